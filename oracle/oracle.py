@@ -1,0 +1,132 @@
+"""ctypes wrapper around oracle/_build/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module; nothing under sdpb_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+SCALARS = ["mu", "P-obj", "D-obj", "gap", "P-err", "p-err", "D-err", "R-err",
+           "P-step", "D-step", "beta", "Q_cond_number", "max_block_cond_number"]
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "sdpb_oracle.cpp")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.orc_create.restype = ctypes.c_void_p
+        L.orc_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        L.orc_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_last_error.restype = ctypes.c_char_p
+        L.orc_last_error.argtypes = [ctypes.c_void_p]
+        L.orc_set_param.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+        L.orc_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 4
+        L.orc_set_block.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_char_p] * 4
+        L.orc_set_objective.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+        L.orc_init_state.argtypes = [ctypes.c_void_p]
+        L.orc_iterate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        L.orc_terminate_reason.argtypes = [ctypes.c_void_p]
+        L.orc_terminate_string.restype = ctypes.c_char_p
+        L.orc_terminate_string.argtypes = [ctypes.c_void_p]
+        L.orc_get_scalar.restype = ctypes.c_char_p
+        L.orc_get_scalar.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.orc_get_array.restype = ctypes.c_char_p
+        L.orc_get_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        L.orc_int_syrk.restype = ctypes.c_char_p
+        L.orc_int_syrk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+        L.orc_scalar_op.restype = ctypes.c_char_p
+        L.orc_scalar_op.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 3
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Oracle:
+    """GMP-mpf restatement of the reference iteration, driven like the product solver."""
+
+    def __init__(self, sdp, precision: int, params: dict | None = None, param_prec: int = 64):
+        from sdpb_amd.sdp_io import block_text  # pure-python I/O helper, no compute
+        self.L = lib()
+        J = sdp.J
+        dims = (ctypes.c_int * J)(*sdp.dims)
+        npts = (ctypes.c_int * J)(*sdp.num_points)
+        self.h = ctypes.c_void_p(self.L.orc_create(precision, J, dims, npts, sdp.N))
+        self.sdp = sdp
+        flags = dict(maxIterations=500, findPrimalFeasible=0, findDualFeasible=0,
+                     detectPrimalFeasibleJump=0, detectDualFeasibleJump=0)
+        for k, v in (params or {}).items():
+            if k in flags:
+                flags[k] = int(v)
+            else:
+                self._chk(self.L.orc_set_param(self.h, k.encode(), str(v).encode(), param_prec))
+        self.L.orc_set_flags(self.h, flags["maxIterations"], flags["findPrimalFeasible"],
+                             flags["findDualFeasible"], flags["detectPrimalFeasibleJump"],
+                             flags["detectDualFeasibleJump"])
+        for j, blk in enumerate(sdp.blocks):
+            self._chk(self.L.orc_set_block(self.h, j, *block_text(blk)))
+        self._chk(self.L.orc_set_objective(self.h, " ".join(sdp.b).encode(),
+                                           sdp.constant.encode()))
+        self._chk(self.L.orc_init_state(self.h))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OracleError(self.L.orc_last_error(self.h).decode())
+
+    def iterate(self) -> bool:
+        """One loop body of SDP_Solver::run; returns True when the loop terminates."""
+        t = ctypes.c_int(0)
+        self._chk(self.L.orc_iterate(self.h, ctypes.byref(t)))
+        return bool(t.value)
+
+    def scalar(self, name: str) -> str:
+        return self.L.orc_get_scalar(self.h, name.encode()).decode()
+
+    def scalars(self) -> dict:
+        d = {k: self.scalar(k) for k in SCALARS}
+        d["block_name"] = self.scalar("block_name")
+        return d
+
+    def array(self, which: str, j: int = 0, parity: int = 0):
+        return self.L.orc_get_array(self.h, which.encode(), j, parity).decode().split()
+
+    @property
+    def terminate_reason(self) -> str:
+        return self.L.orc_terminate_string(self.h).decode()
+
+    def int_syrk(self, rows, cols, ints_colmajor):
+        txt = " ".join(str(v) for v in ints_colmajor).encode()
+        return [int(s) for s in self.L.orc_int_syrk(self.h, rows, cols, txt).decode().split()]
+
+    def scalar_op(self, op, a, b="0"):
+        return self.L.orc_scalar_op(self.h, op.encode(), str(a).encode(), str(b).encode()).decode()
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

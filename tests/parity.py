@@ -1,0 +1,71 @@
+"""Shared comparison helpers for the parity tests.
+
+Tolerances are the reference's own:
+  * relative 2^-99 on every numeric field of every iterations.json record and on
+    out.txt's primalObjective/dualObjective (end-to-end.test.cxx:27, diff.hxx:50-76:
+    |a-b| < 2^-99 (|a|+|b|));
+  * error-like fields are skipped when below 2^-49 (diff_sdpb_out.cxx:270-281).
+"""
+import json
+import os
+import re
+
+import mpmath
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NUMERIC_KEYS = ["mu", "P-obj", "D-obj", "gap", "P-err", "p-err", "D-err", "R-err",
+                "P-step", "D-step", "beta", "Q_cond_number", "max_block_cond_number"]
+ERROR_KEYS = {"P-err", "p-err", "D-err", "R-err"}
+mpmath.mp.prec = 1400
+
+
+def cases():
+    with open(os.path.join(GOLDEN, "cases.json")) as f:
+        return json.load(f)
+
+
+def load_case(name):
+    from sdpb_amd.sdp_io import read_sdp
+    meta = cases()[name]
+    d = os.path.join(GOLDEN, name)
+    sdp = read_sdp(os.path.join(d, "sdp"))
+    with open(os.path.join(d, "iterations.json")) as f:
+        iters = json.load(f)
+    with open(os.path.join(d, "out.txt")) as f:
+        out_txt = f.read()
+    out = {}
+    for m in re.finditer(r"(\w[\w ]*?)\s*=\s*([^;]+);", out_txt):
+        out[m.group(1).strip()] = m.group(2).strip().strip('"')
+    return sdp, meta, iters, out
+
+
+def rel_diff(a, b):
+    a = mpmath.mpf(a)
+    b = mpmath.mpf(b)
+    if a == b:
+        return mpmath.mpf(0)
+    return abs(a - b) / (abs(a) + abs(b))
+
+
+def log2_rel(a, b):
+    r = rel_diff(a, b)
+    return float(mpmath.log(r, 2)) if r > 0 else float("-inf")
+
+
+def compare_iteration(got: dict, want: dict, tol_bits: int = 99, skip_err_below_bits: int = 49):
+    """Return list of (key, log2 relative diff) that violate 2^-tol_bits."""
+    bad = []
+    worst = float("-inf")
+    for k in NUMERIC_KEYS:
+        if k not in want:
+            continue
+        w = mpmath.mpf(want[k])
+        g = mpmath.mpf(got[k])
+        if k in ERROR_KEYS and abs(w) < mpmath.mpf(2) ** -skip_err_below_bits \
+                and abs(g) < mpmath.mpf(2) ** -skip_err_below_bits:
+            continue
+        l2 = log2_rel(g, w)
+        worst = max(worst, l2)
+        if l2 > -tol_bits:
+            bad.append((k, l2))
+    return bad, worst
