@@ -1,0 +1,144 @@
+/* sdpb_hip.h — C ABI of the MI355X-native interior-point step for SDPB's sdp_solve.
+ *
+ * The reference has no plugin/FFI layer; the seam this library replaces is the C++
+ * member SDP_Solver::step() (src/sdp_solve/SDP_Solver.hxx:94-112, defined in
+ * src/sdp_solve/SDP_Solver/run/step/step.cxx:51-229) together with the pre-step half
+ * of the loop body of SDP_Solver::run() (src/sdp_solve/SDP_Solver/run/run.cxx:380-435).
+ * A thin C++ shim inside sdpb keeps the CLI, the SDP reader and the writers and calls
+ * these entry points instead (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - Every call returns int: 0 ok; 1 a Cholesky factorisation met a matrix that is not
+ *    positive definite (message names the block/parity exactly like the reference's
+ *    RUNTIME_ERRORs: cholesky_decomposition.cxx:22-25, compute_Q.cxx:36-38,
+ *    initialize_schur_complement_solver.cxx:100-103); 2 out of device memory; 3 HIP or
+ *    collective failure; 4 bad argument.  sdpb_hip_last_error() returns the text; the
+ *    shim rethrows it as RUNTIME_ERROR so main()'s abort path (src/sdpb/main.cxx:180-188)
+ *    is unchanged.
+ *  - Numbers cross the boundary as decimal strings (what the SDP files and sdpb's
+ *    outputs contain, Json_Block_Data_Parser.hxx:26-36, print_iteration.cxx:91-104);
+ *    lists are whitespace-separated.  They are converted exactly (then truncated to
+ *    the working precision) — El::BigFloat(str) semantics.
+ *  - Calls are synchronous and not re-entrant per context; one host thread per GPU.
+ *  - There is no CPU path: sdpb_hip_create fails with code 3 if no GPU is present.
+ */
+#ifndef SDPB_HIP_H
+#define SDPB_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdpb_hip_ctx sdpb_hip_ctx;
+
+/* Replaces Block_Info (sizes: src/sdp_solve/Block_Info.hxx:54-119), the SDP_Solver
+ * constructor (src/sdp_solve/SDP_Solver/SDP_Solver.cxx:3-51) and
+ * initialize_bigint_syrk_context (run.cxx:250-255).  dims[j] = m_j, num_points[j] =
+ * K_j (block_info_<j>.json), N = length of b.  Blocks are assigned to ranks by a
+ * deterministic cost model (analogue of compute_block_grid_mapping.hxx:58-183);
+ * rank/world_size describe this process (one process per GPU).  device_id < 0 keeps
+ * the current device. */
+int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
+                    int rank, int world_size, sdpb_hip_ctx **out);
+void sdpb_hip_destroy(sdpb_hip_ctx *ctx);
+/* ctx may be NULL: message of the last failed sdpb_hip_create on this thread. */
+const char *sdpb_hip_last_error(sdpb_hip_ctx *ctx);
+
+/* Solver_Parameters (src/sdp_solve/Solver_Parameters.hxx:13-30).  name is the sdpb
+ * option name: dualityGapThreshold, primalErrorThreshold, dualErrorThreshold,
+ * initialMatrixScalePrimal, initialMatrixScaleDual, feasibleCenteringParameter,
+ * infeasibleCenteringParameter, stepLengthReduction, maxComplementarity,
+ * minPrimalStep, minDualStep.  Defaults are Solver_Parameters.cxx:10-157. */
+int sdpb_hip_set_param(sdpb_hip_ctx *ctx, const char *name, const char *value);
+int sdpb_hip_set_flags(sdpb_hip_ctx *ctx, long max_iterations, int find_primal_feasible, int find_dual_feasible,
+                       int detect_primal_feasible_jump, int detect_dual_feasible_jump);
+
+/* struct SDP (src/sdp_solve/SDP.hxx:74-122).  Row-major lists exactly as in
+ * block_data_<j>.json: bilinear_bases_even/odd[row][k], B[p][n], c[p]. Blocks owned by
+ * another rank are accepted and ignored, so every rank may be fed the whole SDP. */
+int sdpb_hip_set_block(sdpb_hip_ctx *ctx, int j, const char *bilinear_bases_even, const char *bilinear_bases_odd,
+                       const char *B, const char *c);
+/* objectives.json: "b" and "constant" (src/sdp_solve/SDP/read_objectives.cxx:22-36). */
+int sdpb_hip_set_objective(sdpb_hip_ctx *ctx, const char *b, const char *constant);
+
+/* x = 0, y = 0, X = initialMatrixScalePrimal * I, Y = initialMatrixScaleDual * I
+ * (SDP_Solver.cxx:23-38). */
+int sdpb_hip_init_state(sdpb_hip_ctx *ctx);
+
+/* One pass of the loop body of SDP_Solver::run (run.cxx:380-435): objectives,
+ * Cholesky of X and Y, bilinear pairings, residues and errors, feasibility/termination
+ * test, then SDP_Solver::step.  *terminated = 1 when the reference loop would `break`
+ * (reason via sdpb_hip_terminate_reason); maxRuntime and checkpointing stay with the
+ * caller's loop.  Collective over all ranks. */
+int sdpb_hip_iterate(sdpb_hip_ctx *ctx, int *terminated);
+/* SDP_Solver_Terminate_Reason (src/sdp_solve/SDP_Solver_Terminate_Reason.hxx:6-19) in
+ * declaration order, -1 while running; the string is operator<<'s text
+ * (SDP_Solver_Terminate_Reason.cxx:4-45). */
+int sdpb_hip_terminate_reason(sdpb_hip_ctx *ctx);
+const char *sdpb_hip_terminate_string(sdpb_hip_ctx *ctx);
+
+/* Per-iteration scalars under their iterations.json keys (print_iteration.cxx:91-104):
+ * mu P-obj D-obj gap P-err p-err D-err R-err P-step D-step beta Q_cond_number
+ * max_block_cond_number block_name; and out.txt keys (src/sdpb/save_solution.cxx:32-37):
+ * primalObjective dualObjective dualityGap primalError dualError.  Writes a
+ * NUL-terminated decimal string; returns 4 if buf is too small (*needed = size). */
+int sdpb_hip_get_scalar(sdpb_hip_ctx *ctx, const char *name, char *buf, size_t buflen, size_t *needed);
+
+/* Solver state and work arrays, column-major, one decimal per line.  which: x X y Y
+ * (SDP_Solver.hxx:28-43; checkpoint / save_solution.cxx:67-150), dx dX dy dY,
+ * dual_residues primal_residues primal_residue_p, Q S AXinv AY ...  j = global block
+ * index (must be owned by this rank), parity 0/1 for block-diagonal members. */
+int sdpb_hip_get_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, char *buf, size_t buflen,
+                       size_t *needed);
+/* Inject x, X, y or Y (text checkpoint: load_text_checkpoint.cxx:6-44). */
+int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, const char *values);
+
+/* Rank that owns block j (block_info.block_indices in the reference). */
+int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j);
+/* 32-bit limbs of the device mantissa chosen for precision_bits. */
+int sdpb_hip_limbs(sdpb_hip_ctx *ctx);
+
+/* Cross-GPU exchange (world_size > 1), replacing the El::mpi collectives listed in
+ * SURVEY.md §2a.  The library hands DEVICE pointers it owns to these callbacks:
+ *   allreduce_sum_u64: in-place SUM over ranks of count uint64 (the fixed-point image
+ *     of the partial Q = P^T P; restore_and_reduce.cxx:137-212 in the reference);
+ *   allgather_bytes: rank-ordered gather of `bytes` from every rank (small vectors and
+ *     scalars: dy, column norms, mu, errors, lambda_min; El::mpi::AllReduce sites).
+ * Return 0 on success.  With RCCL: ncclAllReduce(ncclUint64, ncclSum) / ncclAllGather. */
+typedef struct
+{
+  int (*allreduce_sum_u64)(void *user, void *dev_ptr, size_t count);
+  int (*allgather_bytes)(void *user, const void *dev_send, void *dev_recv, size_t bytes);
+  void *user;
+} sdpb_hip_collectives;
+int sdpb_hip_set_collectives(sdpb_hip_ctx *ctx, const sdpb_hip_collectives *c);
+
+/* Accumulated wall time per stage in ms as a JSON object; names follow the reference's
+ * Scoped_Timer hierarchy below "run.iter_*." (SURVEY.md §5). */
+int sdpb_hip_timers(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed);
+
+/* Block -> rank plan without a context or a GPU (pure host logic). owners[j] out. */
+int sdpb_hip_plan_blocks(int num_blocks, const int *dims, const int *num_points, int N, int world_size, int *owners);
+
+/* ---- operator-level entry points used by the parity tests ------------------- */
+/* Device arithmetic on one pair of numbers: op in add sub mul div sqrt. */
+int sdpb_hip_op_scalar(sdpb_hip_ctx *ctx, const char *op, const char *a, const char *b, char *buf, size_t buflen,
+                       size_t *needed);
+/* Exact integer Q = P^T P with the fixed-point syrk kernel (the semantics of
+ * BigInt_Shared_Memory_Syrk_Context::bigint_syrk_blas, bigint_syrk_blas.cxx:183-302).
+ * P: rows x cols decimal integers, column-major; result: lower triangle of the
+ * cols x cols product, column-major, one integer per line. */
+int sdpb_hip_op_int_syrk(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, char *buf, size_t buflen,
+                         size_t *needed);
+/* Host-side fixed-point exchange image helpers (used by the world_size-2 gloo tests to
+ * check the u64-lane reduction without a GPU): encode a two's-complement integer given
+ * in decimal into `planes` 32-bit limbs widened to uint64 lanes; decode after a lane-wise
+ * sum with carry propagation. */
+int sdpb_hip_host_encode_u64(const char *decimal_integer, int planes, unsigned long long *lanes);
+int sdpb_hip_host_decode_u64(const unsigned long long *lanes, int planes, char *buf, size_t buflen, size_t *needed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDPB_HIP_H */

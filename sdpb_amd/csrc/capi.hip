@@ -1,0 +1,308 @@
+// capi.hip — the C ABI declared in include/sdpb_hip.h.
+#include "../../include/sdpb_hip.h"
+
+#include "solver.hpp"
+
+#include <cstring>
+#include <memory>
+
+struct sdpb_hip_ctx
+{
+  std::unique_ptr<sdpb::SolverBase> solver;
+  std::string error, strbuf;
+};
+
+namespace
+{
+thread_local std::string g_create_error;
+
+int fail(sdpb_hip_ctx *ctx, int code, const std::string &msg)
+{
+  if(ctx)
+    ctx->error = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+template <class F> int guarded(sdpb_hip_ctx *ctx, F f)
+{
+  if(!ctx)
+    return fail(nullptr, 4, "null context");
+  try
+    {
+      f();
+      return 0;
+    }
+  catch(sdpb::SolverError &e)
+    {
+      return fail(ctx, e.code, e.what());
+    }
+  catch(sdpb::HipError &e)
+    {
+      return fail(ctx, e.code, e.what());
+    }
+  catch(std::bad_alloc &)
+    {
+      return fail(ctx, 2, "out of host memory");
+    }
+  catch(std::exception &e)
+    {
+      return fail(ctx, 4, e.what());
+    }
+}
+int copy_out(sdpb_hip_ctx *ctx, const std::string &s, char *buf, size_t buflen, size_t *needed)
+{
+  if(needed)
+    *needed = s.size() + 1;
+  if(!buf || buflen < s.size() + 1)
+    return fail(ctx, 4, "output buffer too small");
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return 0;
+}
+} // namespace
+
+extern "C" {
+
+int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
+                    int rank, int world_size, sdpb_hip_ctx **out)
+{
+  if(!out || !dims || !num_points || num_blocks <= 0 || world_size < 1 || rank < 0 || rank >= world_size)
+    return fail(nullptr, 4, "sdpb_hip_create: bad argument");
+  *out = nullptr;
+  try
+    {
+      int ndev = 0;
+      if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, 3, "sdpb_hip_create: no HIP device found — this library has no CPU path");
+      if(device_id >= 0)
+        HIP_CHECK(hipSetDevice(device_id));
+      std::vector<int> d(dims, dims + num_blocks), k(num_points, num_points + num_blocks);
+      for(int j = 0; j < num_blocks; ++j)
+        if(d[j] <= 0 || k[j] <= 0)
+          return fail(nullptr, 4, "sdpb_hip_create: dim and num_points must be positive");
+      const int want = mw::limbs_for_precision(precision_bits);
+      std::unique_ptr<sdpb_hip_ctx> ctx(new sdpb_hip_ctx);
+      sdpb::SolverBase *s = nullptr;
+      // round the request up to the next compiled mantissa width ("GMP will round this
+      // up", Solver_Parameters.cxx:26-28)
+      if(want <= 6) s = sdpb::make_solver_6(precision_bits, d, k, N, rank, world_size);
+      else if(want <= 10) s = sdpb::make_solver_10(precision_bits, d, k, N, rank, world_size);
+      else if(want <= 16) s = sdpb::make_solver_16(precision_bits, d, k, N, rank, world_size);
+      else if(want <= 18) s = sdpb::make_solver_18(precision_bits, d, k, N, rank, world_size);
+      else if(want <= 24) s = sdpb::make_solver_24(precision_bits, d, k, N, rank, world_size);
+      else if(want <= 26) s = sdpb::make_solver_26(precision_bits, d, k, N, rank, world_size);
+      else if(want <= 34) s = sdpb::make_solver_34(precision_bits, d, k, N, rank, world_size);
+      else
+        return fail(nullptr, 4, "sdpb_hip_create: precision above 1024 bits is not compiled in");
+      ctx->solver.reset(s);
+      *out = ctx.release();
+      return 0;
+    }
+  catch(sdpb::SolverError &e)
+    {
+      return fail(nullptr, e.code, e.what());
+    }
+  catch(sdpb::HipError &e)
+    {
+      return fail(nullptr, e.code, e.what());
+    }
+  catch(std::exception &e)
+    {
+      return fail(nullptr, 4, e.what());
+    }
+}
+
+void sdpb_hip_destroy(sdpb_hip_ctx *ctx) { delete ctx; }
+
+const char *sdpb_hip_last_error(sdpb_hip_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int sdpb_hip_set_param(sdpb_hip_ctx *ctx, const char *name, const char *value)
+{
+  return guarded(ctx, [&] { ctx->solver->set_param(name, value); });
+}
+int sdpb_hip_set_flags(sdpb_hip_ctx *ctx, long max_iterations, int fpf, int fdf, int dpfj, int ddfj)
+{
+  return guarded(ctx, [&] { ctx->solver->set_flags(max_iterations, fpf, fdf, dpfj, ddfj); });
+}
+int sdpb_hip_set_block(sdpb_hip_ctx *ctx, int j, const char *be, const char *bo, const char *B, const char *c)
+{
+  return guarded(ctx, [&] { ctx->solver->set_block(j, be, bo, B, c); });
+}
+int sdpb_hip_set_objective(sdpb_hip_ctx *ctx, const char *b, const char *constant)
+{
+  return guarded(ctx, [&] { ctx->solver->set_objective(b, constant); });
+}
+int sdpb_hip_init_state(sdpb_hip_ctx *ctx)
+{
+  return guarded(ctx, [&] { ctx->solver->init_state(); });
+}
+int sdpb_hip_iterate(sdpb_hip_ctx *ctx, int *terminated)
+{
+  return guarded(ctx, [&] {
+    const bool t = ctx->solver->iterate();
+    if(terminated)
+      *terminated = t ? 1 : 0;
+  });
+}
+int sdpb_hip_terminate_reason(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->terminate_reason() : -1; }
+const char *sdpb_hip_terminate_string(sdpb_hip_ctx *ctx)
+{
+  return ctx ? sdpb::terminate_string(ctx->solver->terminate_reason()) : "";
+}
+int sdpb_hip_get_scalar(sdpb_hip_ctx *ctx, const char *name, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] { ctx->strbuf = ctx->solver->get_scalar(name); });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
+}
+int sdpb_hip_get_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] { ctx->strbuf = ctx->solver->get_array(which, j, parity); });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
+}
+int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, const char *values)
+{
+  return guarded(ctx, [&] { ctx->solver->set_array(which, j, parity, values); });
+}
+int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j)
+{
+  int r = -1;
+  guarded(ctx, [&] { r = ctx->solver->block_owner(j); });
+  return r;
+}
+int sdpb_hip_limbs(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->limbs() : 0; }
+
+int sdpb_hip_set_collectives(sdpb_hip_ctx *ctx, const sdpb_hip_collectives *c)
+{
+  return guarded(ctx, [&] {
+    sdpb::Collectives cc;
+    if(c)
+      {
+        cc.allreduce_sum_u64 = c->allreduce_sum_u64;
+        cc.allgather_bytes = c->allgather_bytes;
+        cc.user = c->user;
+      }
+    ctx->solver->set_collectives(cc);
+  });
+}
+int sdpb_hip_timers(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] { ctx->strbuf = ctx->solver->timers_json(); });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
+}
+
+int sdpb_hip_plan_blocks(int num_blocks, const int *dims, const int *num_points, int N, int world_size, int *owners)
+{
+  if(num_blocks <= 0 || !dims || !num_points || !owners || world_size < 1)
+    return 4;
+  std::vector<int> d(dims, dims + num_blocks), k(num_points, num_points + num_blocks);
+  const std::vector<int> o = sdpb::plan_block_owners(d, k, N, world_size);
+  std::copy(o.begin(), o.end(), owners);
+  return 0;
+}
+
+int sdpb_hip_op_scalar(sdpb_hip_ctx *ctx, const char *op, const char *a, const char *b, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] { ctx->strbuf = ctx->solver->op_scalar(op, a, b); });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
+}
+int sdpb_hip_op_int_syrk(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] { ctx->strbuf = ctx->solver->op_int_syrk(rows, cols, P); });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
+}
+
+int sdpb_hip_host_encode_u64(const char *s, int planes, unsigned long long *lanes)
+{
+  if(!s || !lanes || planes <= 0)
+    return 4;
+  bool negative = false;
+  if(*s == '-')
+    {
+      negative = true;
+      ++s;
+    }
+  mw::BigNat n;
+  for(; *s; ++s)
+    {
+      if(*s < '0' || *s > '9')
+        return 4;
+      if(n.w.empty())
+        {
+          if(*s != '0')
+            n.w.push_back((uint32_t)(*s - '0'));
+        }
+      else
+        n.mul_small(10, (uint32_t)(*s - '0'));
+    }
+  if((int)n.w.size() >= planes)
+    return 4;
+  std::vector<uint32_t> w(planes, 0);
+  std::copy(n.w.begin(), n.w.end(), w.begin());
+  if(negative && !n.w.empty())
+    {
+      uint64_t carry = 1;
+      for(auto &x : w)
+        {
+          const uint64_t t = (uint64_t)(~x) + carry;
+          x = (uint32_t)t;
+          carry = t >> 32;
+        }
+    }
+  for(int k = 0; k < planes; ++k)
+    lanes[k] = w[k];
+  return 0;
+}
+int sdpb_hip_host_decode_u64(const unsigned long long *lanes, int planes, char *buf, size_t buflen, size_t *needed)
+{
+  if(!lanes || planes <= 0)
+    return 4;
+  mw::BigNat n;
+  n.w.resize(planes);
+  unsigned long long carry = 0;
+  for(int k = 0; k < planes; ++k)
+    {
+      const unsigned long long t = lanes[k] + carry;
+      n.w[k] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  const bool negative = n.w[planes - 1] >> 31;
+  if(negative)
+    {
+      uint64_t c = 1;
+      for(auto &x : n.w)
+        {
+          const uint64_t t = (uint64_t)(~x) + c;
+          x = (uint32_t)t;
+          c = t >> 32;
+        }
+    }
+  n.trim();
+  std::string dig;
+  while(!n.is_zero())
+    {
+      uint32_t rem = n.div_small(1000000000u);
+      for(int k = 0; k < 9; ++k)
+        {
+          dig.push_back((char)('0' + rem % 10));
+          rem /= 10;
+        }
+    }
+  while(!dig.empty() && dig.back() == '0')
+    dig.pop_back();
+  std::string out;
+  if(dig.empty())
+    out = "0";
+  else
+    {
+      if(negative)
+        dig.push_back('-');
+      out.assign(dig.rbegin(), dig.rend());
+    }
+  if(needed)
+    *needed = out.size() + 1;
+  if(!buf || buflen < out.size() + 1)
+    return 4;
+  std::memcpy(buf, out.c_str(), out.size() + 1);
+  return 0;
+}
+} // extern "C"

@@ -1,0 +1,952 @@
+// kernels.hpp — HIP kernels (gfx950) for one interior-point iteration of sdp_solve.
+//
+// Work decomposition: SDP blocks are independent, so every per-block
+// operation is a batched launch — blockIdx.y (or blockIdx.x for workgroup-per-matrix
+// kernels) selects the matrix through a descriptor table, threads of a 256-lane
+// workgroup (4 wavefronts of 64) own output elements.  Each lane carries whole
+// multi-word numbers in VGPRs (mw.hpp); with limb-major storage a wavefront's loads
+// of "limb l of 64 consecutive elements" are single coalesced 256-B transactions.
+// The arithmetic intensity is ~NL^2/2 integer MACs per 4(NL+1) bytes, so these
+// kernels are bound by the v_mad_u64_u32 pipe, not by HBM.
+//
+// Reference functions each kernel replaces are cited at the kernel.
+#pragma once
+#include "dev.hpp"
+
+namespace sdpb
+{
+using mw::Mw;
+constexpr int WG = 256; // workgroup size used by every kernel
+
+template <int NL> MW_HD Mw<NL> mat_ld(const Batch &b, const MatDesc &d, int i, int j)
+{
+  return mw::load<NL>(b.p, (size_t)d.off + (size_t)i + (size_t)j * (size_t)d.ld);
+}
+template <int NL> MW_HD void mat_st(const Batch &b, const MatDesc &d, int i, int j, const Mw<NL> &v)
+{
+  mw::store<NL>(b.p, (size_t)d.off + (size_t)i + (size_t)j * (size_t)d.ld, v);
+}
+
+// ---------------------------------------------------------------------------
+// Generic element-wise and reduction drivers
+// ---------------------------------------------------------------------------
+template <class F> __global__ void __launch_bounds__(WG) k_foreach(size_t count, F f)
+{
+  for(size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < count; i += (size_t)gridDim.x * WG)
+    f(i);
+}
+
+enum ReduceOp
+{
+  RED_SUM = 0,
+  RED_MAX = 1,
+  RED_MIN = 2
+};
+template <int NL, int OP> MW_HD Mw<NL> red_combine(const Mw<NL> &a, const Mw<NL> &b)
+{
+  if(OP == RED_SUM)
+    return mw::add(a, b);
+  if(OP == RED_MAX)
+    return mw::max(a, b);
+  return mw::min(a, b);
+}
+// Workgroup tree reduction through LDS; result valid in thread 0.
+template <int NL, int OP> __device__ Mw<NL> wg_reduce(Mw<NL> v, bool has)
+{
+  __shared__ Mw<NL> sm[WG];
+  __shared__ int sh[WG];
+  const int t = threadIdx.x;
+  sm[t] = v;
+  sh[t] = has ? 1 : 0;
+  __syncthreads();
+  for(int s = WG / 2; s > 0; s >>= 1)
+    {
+      if(t < s && sh[t + s])
+        {
+          if(sh[t])
+            sm[t] = red_combine<NL, OP>(sm[t], sm[t + s]);
+          else
+            {
+              sm[t] = sm[t + s];
+              sh[t] = 1;
+            }
+        }
+      __syncthreads();
+    }
+  Mw<NL> r = sm[0];
+  __syncthreads();
+  return r;
+}
+// out[blockIdx.x] = OP over f(i), i in this block's grid-stride range; empty -> 0
+template <int NL, int OP, class F> __global__ void __launch_bounds__(WG) k_reduce(size_t count, F f, mw::Ptr out)
+{
+  Mw<NL> acc = mw::zero<NL>();
+  bool has = false;
+  for(size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < count; i += (size_t)gridDim.x * WG)
+    {
+      const Mw<NL> v = f(i);
+      acc = has ? red_combine<NL, OP>(acc, v) : v;
+      has = true;
+    }
+  const Mw<NL> r = wg_reduce<NL, OP>(acc, has);
+  if(threadIdx.x == 0)
+    mw::store<NL>(out, blockIdx.x, r);
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky, lower, in place; one workgroup per matrix.  Also writes 1/L_ii.
+// Replaces El::Cholesky(LOWER, .) at cholesky_decomposition.cxx:17 (X, Y blocks)
+// and compute_Q.cxx:31 (Schur blocks); the diagonal block of the blocked
+// Cholesky(Q) (initialize_schur_complement_solver.cxx:98) uses it too.
+// fail[q] = 1 + (index of the non-positive pivot) if the matrix is not PD.
+// ---------------------------------------------------------------------------
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_lower(Batch A, Batch invd, int *fail)
+{
+  const int q = blockIdx.x;
+  const MatDesc d = A.d[q];
+  const MatDesc dv = invd.d[q];
+  const int n = d.rows, t = threadIdx.x;
+  __shared__ Mw<NL> s_inv;
+  __shared__ int s_fail;
+  if(t == 0)
+    s_fail = 0;
+  __syncthreads();
+  for(int j = 0; j < n; ++j)
+    {
+      if(t == 0)
+        {
+          const Mw<NL> dj = mat_ld<NL>(A, d, j, j);
+          if(mw::is_zero(dj) || dj.neg)
+            s_fail = j + 1;
+          else
+            {
+              const Mw<NL> r = mw::rsqrt(dj);
+              Mw<NL> s = mw::mul(dj, r);
+              s = mw::add(s, mw::mul_2exp(mw::mul(r, mw::sub(dj, mw::mul(s, s))), -1));
+              mat_st<NL>(A, d, j, j, s);
+              // 1/s refined from r: inv = r*(2 - s*r)
+              const Mw<NL> inv = mw::mul(r, mw::sub(mw::from_u32<NL>(2), mw::mul(s, r)));
+              s_inv = inv;
+              mw::store<NL>(invd.p, (size_t)dv.off + j, inv);
+            }
+        }
+      __syncthreads();
+      if(s_fail)
+        {
+          if(t == 0)
+            fail[q] = s_fail;
+          return;
+        }
+      const Mw<NL> inv = s_inv;
+      for(int i = j + 1 + t; i < n; i += WG)
+        mat_st<NL>(A, d, i, j, mw::mul(mat_ld<NL>(A, d, i, j), inv));
+      __syncthreads();
+      const int m = n - j - 1;
+      for(int idx = t; idx < m * m; idx += WG)
+        {
+          const int c = j + 1 + idx / m, r = j + 1 + idx % m;
+          if(r >= c)
+            mat_st<NL>(A, d, r, c, mw::fms(mat_ld<NL>(A, d, r, j), mat_ld<NL>(A, d, c, j), mat_ld<NL>(A, d, r, c)));
+        }
+      __syncthreads();
+    }
+  // El::Cholesky leaves the other triangle untouched; callers here expect zeros
+  for(int idx = t; idx < n * n; idx += WG)
+    {
+      const int c = idx / n, r = idx % n;
+      if(r < c)
+        mat_st<NL>(A, d, r, c, mw::zero<NL>());
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Triangular solves with many independent right-hand sides: one lane per RHS.
+// L lower, invd = 1/diag(L).   grid = (ceil(max_vectors/WG), batch)
+// ---------------------------------------------------------------------------
+// X := L^{-1} X   (El::Trsm LEFT,LOWER,NORMAL; compute_A_X_inv.cxx:21,
+// cholesky_solve.cxx:9, lower_triangular_inverse_congruence.cxx:12)
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_lln(Batch L, Batch invd, Batch X)
+{
+  const int q = blockIdx.y;
+  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
+  const int c = blockIdx.x * WG + threadIdx.x;
+  if(c >= dx.cols)
+    return;
+  const int n = dl.rows;
+  for(int i = 0; i < n; ++i)
+    {
+      Mw<NL> acc = mat_ld<NL>(X, dx, i, c);
+      for(int k = 0; k < i; ++k)
+        acc = mw::fms(mat_ld<NL>(L, dl, i, k), mat_ld<NL>(X, dx, k, c), acc);
+      mat_st<NL>(X, dx, i, c, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + i)));
+    }
+}
+// X := L^{-T} X   (El::Trsm LEFT,LOWER,TRANSPOSE; cholesky_solve.cxx:9)
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_llt(Batch L, Batch invd, Batch X)
+{
+  const int q = blockIdx.y;
+  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
+  const int c = blockIdx.x * WG + threadIdx.x;
+  if(c >= dx.cols)
+    return;
+  const int n = dl.rows;
+  for(int i = n - 1; i >= 0; --i)
+    {
+      Mw<NL> acc = mat_ld<NL>(X, dx, i, c);
+      for(int k = i + 1; k < n; ++k)
+        acc = mw::fms(mat_ld<NL>(L, dl, k, i), mat_ld<NL>(X, dx, k, c), acc);
+      mat_st<NL>(X, dx, i, c, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + i)));
+    }
+}
+// X := X L^{-T}   (El::Trsm RIGHT,LOWER,TRANSPOSE; lower_triangular_inverse_
+// congruence.cxx:8).  With B stored transposed (N x P_j) this is also
+// schur_off_diagonal = L^{-1} B (compute_Q.cxx:48): P^T = B^T L^{-T}; one lane per
+// row, rows are contiguous so every load is coalesced.
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt(Batch L, Batch invd, Batch X)
+{
+  const int q = blockIdx.y;
+  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
+  const int r = blockIdx.x * WG + threadIdx.x;
+  if(r >= dx.rows)
+    return;
+  const int n = dl.rows;
+  for(int j = 0; j < n; ++j)
+    {
+      Mw<NL> acc = mat_ld<NL>(X, dx, r, j);
+      for(int k = 0; k < j; ++k)
+        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, j, k), acc);
+      mat_st<NL>(X, dx, r, j, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + j)));
+    }
+}
+
+// Single right-hand side per matrix: workgroup-cooperative, right-looking.
+// x := L^{-1} x (lower_triangular_solve.hxx:10-17 on dx; first half of
+// El::cholesky::SolveAfter on dy) — TRANS=true: x := L^{-T} x
+// (lower_triangular_transpose_solve.cxx:6-13; second half of SolveAfter).
+template <int NL, bool TRANS> __global__ void __launch_bounds__(WG) k_vec_solve(Batch L, Batch invd, Batch x)
+{
+  const int q = blockIdx.x;
+  const MatDesc dl = L.d[q], dv = invd.d[q], dx = x.d[q];
+  const int n = dl.rows, t = threadIdx.x;
+  __shared__ Mw<NL> s_x;
+  for(int s = 0; s < n; ++s)
+    {
+      const int k = TRANS ? n - 1 - s : s;
+      if(t == 0)
+        {
+          const Mw<NL> v = mw::mul(mw::load<NL>(x.p, (size_t)dx.off + k), mw::load<NL>(invd.p, (size_t)dv.off + k));
+          mw::store<NL>(x.p, (size_t)dx.off + k, v);
+          s_x = v;
+        }
+      __syncthreads();
+      const Mw<NL> xk = s_x;
+      if(!TRANS)
+        for(int i = k + 1 + t; i < n; i += WG)
+          mw::store<NL>(x.p, (size_t)dx.off + i,
+                        mw::fms(mat_ld<NL>(L, dl, i, k), xk, mw::load<NL>(x.p, (size_t)dx.off + i)));
+      else
+        for(int i = t; i < k; i += WG)
+          mw::store<NL>(x.p, (size_t)dx.off + i,
+                        mw::fms(mat_ld<NL>(L, dl, k, i), xk, mw::load<NL>(x.p, (size_t)dx.off + i)));
+      __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Batched GEMM, one lane per output element, 16x16 output tile per workgroup.
+//   C = (+/-) op(A) B (+ C),   op = transpose if TA
+// sym: only tiles on/below the diagonal are computed and mirrored (El::Syrk LOWER +
+// MakeSymmetric, compute_A_X_inv.cxx:28-29; compute_A_Y.cxx:35,45).
+// Replaces El::Gemm at compute_A_Y.cxx:32,35, scale_multiply_add.cxx:10.
+// ---------------------------------------------------------------------------
+template <int NL, bool TA>
+__global__ void __launch_bounds__(WG) k_gemm(Batch A, Batch B, Batch C, int alpha_neg, int beta_one, int sym)
+{
+  const int q = blockIdx.y;
+  const MatDesc da = A.d[q], db = B.d[q], dc = C.d[q];
+  const int M = dc.rows, Nn = dc.cols, K = TA ? da.rows : da.cols;
+  const int tiles_i = (M + 15) / 16, tiles_j = (Nn + 15) / 16;
+  const int tile = blockIdx.x;
+  if(tile >= tiles_i * tiles_j)
+    return;
+  const int ti = tile % tiles_i, tj = tile / tiles_i;
+  if(sym && tj > ti)
+    return;
+  const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
+  if(i >= M || j >= Nn || (sym && j > i))
+    return;
+  Mw<NL> acc = mw::zero<NL>();
+  for(int k = 0; k < K; ++k)
+    {
+      const Mw<NL> a = TA ? mat_ld<NL>(A, da, k, i) : mat_ld<NL>(A, da, i, k);
+      acc = mw::fma(a, mat_ld<NL>(B, db, k, j), acc);
+    }
+  if(alpha_neg)
+    acc = mw::neg(acc);
+  if(beta_one)
+    acc = mw::add(acc, mat_ld<NL>(C, dc, i, j));
+  mat_st<NL>(C, dc, i, j, acc);
+  if(sym && i != j)
+    mat_st<NL>(C, dc, j, i, acc);
+}
+
+// A = (A + A^T)/2, optionally negated (Block_Diagonal_Matrix::symmetrize, :95-109)
+template <int NL> __global__ void __launch_bounds__(WG) k_symmetrize(Batch A, int negate)
+{
+  const int q = blockIdx.y;
+  const MatDesc d = A.d[q];
+  const int idx = blockIdx.x * WG + threadIdx.x;
+  if(idx >= d.rows * d.rows)
+    return;
+  const int i = idx % d.rows, j = idx / d.rows;
+  if(i < j)
+    return;
+  Mw<NL> s = mw::mul_2exp(mw::add(mat_ld<NL>(A, d, i, j), mat_ld<NL>(A, d, j, i)), -1);
+  if(negate)
+    s = mw::neg(s);
+  mat_st<NL>(A, d, i, j, s);
+  if(i != j)
+    mat_st<NL>(A, d, j, i, s);
+}
+
+// C(i,j) -= sum_k A(i,k) A(j,k), i >= j : trailing update of the blocked Cholesky(Q)
+template <int NL> __global__ void __launch_bounds__(WG) k_syrk_down_lower(Batch A, Batch C)
+{
+  const int q = blockIdx.y;
+  const MatDesc da = A.d[q], dc = C.d[q];
+  const int M = dc.rows, K = da.cols;
+  const int tiles = (M + 15) / 16;
+  // lower-triangular tile index -> (ti,tj), tj <= ti
+  int tile = blockIdx.x;
+  if(tile >= tiles * (tiles + 1) / 2)
+    return;
+  int ti = 0;
+  while((ti + 1) * (ti + 2) / 2 <= tile)
+    ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
+  if(i >= M || j > i)
+    return;
+  Mw<NL> acc = mat_ld<NL>(C, dc, i, j);
+  for(int k = 0; k < K; ++k)
+    acc = mw::fms(mat_ld<NL>(A, da, i, k), mat_ld<NL>(A, da, j, k), acc);
+  mat_st<NL>(C, dc, i, j, acc);
+}
+
+// ---------------------------------------------------------------------------
+// Block-structure helpers shared by the SDP-specific kernels
+// ---------------------------------------------------------------------------
+struct BlockDesc // one SDP block j (local index)
+{
+  int m, K, P;            // dim, num_points, schur size (Block_Info.hxx:54-58)
+  int rows[2], n[2];      // bilinear basis heights, psd sizes (Block_Info.hxx:86-114)
+  unsigned long long voff; // offset of this block's length-P vectors (x, c, dx, d)
+  int global_index;
+};
+// p in [0,P) -> (column_block, row_block, k) with p = ((cb(cb+1))/2 + rb) K + k
+MW_HD void decode_p(int p, int K, int &cb, int &rb, int &k)
+{
+  const int t = p / K;
+  k = p - t * K;
+  cb = 0;
+  while((cb + 1) * (cb + 2) / 2 <= t)
+    ++cb;
+  rb = t - cb * (cb + 1) / 2;
+}
+
+// bases_blocks[2j+b] = I_m (x) bilinear_bases[2j+b]   (set_bases_blocks.cxx:3-22)
+template <int NL> __global__ void __launch_bounds__(WG) k_build_bases_block(Batch bases, Batch E, const BlockDesc *blk)
+{
+  const int q = blockIdx.y;
+  const MatDesc de = E.d[q], dbs = bases.d[q];
+  const int rs = blk[q >> 1].rows[q & 1], K = blk[q >> 1].K;
+  const int idx = blockIdx.x * WG + threadIdx.x;
+  if(idx >= de.rows * de.cols)
+    return;
+  const int row = idx % de.rows, col = idx / de.rows;
+  Mw<NL> v = mw::zero<NL>();
+  if(row / rs == col / K)
+    v = mat_ld<NL>(bases, dbs, row % rs, col % K);
+  mat_st<NL>(E, de, row, col, v);
+}
+
+// Schur complement assembly (compute_schur_complement.cxx:15-125): element-wise in
+// the pairing tiles, lower triangle computed and mirrored (MakeSymmetric LOWER :121).
+// AX, AY batches are indexed 2j+parity; S by j.
+template <int NL>
+__global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Batch S, const BlockDesc *blk)
+{
+  const int j = blockIdx.y;
+  const MatDesc ds = S.d[j];
+  const int P = ds.rows, K = blk[j].K;
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)P * P)
+    return;
+  const int R = (int)(idx % P), C = (int)(idx / P);
+  if(R < C)
+    return;
+  int c0, r0, row, c1, r1, col;
+  decode_p(R, K, c0, r0, row);
+  decode_p(C, K, c1, r1, col);
+  Mw<NL> e = mw::zero<NL>();
+  for(int b = 0; b < 2; ++b)
+    {
+      const MatDesc dx = AX.d[2 * j + b], dy = AY.d[2 * j + b];
+      // A_X_inv tile [cb][rb](r,c) = AX(cb K + r, rb K + c)  (compute_A_X_inv.cxx:39-56)
+      // A_Y tile     [cb][rb](r,c) = AY(cb K + c, rb K + r)  (compute_A_Y.cxx:47-64)
+#define AXT(cb, rb) mat_ld<NL>(AX, dx, (cb)*K + row, (rb)*K + col)
+#define AYT(cb, rb) mat_ld<NL>(AY, dy, (cb)*K + col, (rb)*K + row)
+      e = mw::fma(AXT(c0, r1), AYT(c1, r0), e);
+      e = mw::fma(AXT(r0, r1), AYT(c1, c0), e);
+      e = mw::fma(AXT(c0, c1), AYT(r1, r0), e);
+      e = mw::fma(AXT(r0, c1), AYT(r1, c0), e);
+#undef AXT
+#undef AYT
+    }
+  e = mw::mul_2exp(e, -2);
+  mat_st<NL>(S, ds, R, C, e);
+  if(R != C)
+    mat_st<NL>(S, ds, C, R, e);
+}
+
+// dual_residues[p] = c[p] - sum_b diag(A_Y tile)[k] - (B y)[p]
+// (compute_dual_residues_and_error.cxx:7-66).  BT is B^T (N x P), one lane per p.
+template <int NL>
+__global__ void __launch_bounds__(WG)
+  k_dual_residues(Batch AY, Batch BT, mw::CPtr c, mw::CPtr y, mw::Ptr d, const BlockDesc *blk, int N)
+{
+  const int j = blockIdx.y;
+  const BlockDesc bl = blk[j];
+  const int p = blockIdx.x * WG + threadIdx.x;
+  if(p >= bl.P)
+    return;
+  int cb, rb, k;
+  decode_p(p, bl.K, cb, rb, k);
+  Mw<NL> acc = mw::load<NL>(c, (size_t)bl.voff + p);
+  for(int b = 0; b < 2; ++b)
+    {
+      const MatDesc dy = AY.d[2 * j + b];
+      acc = mw::sub(acc, mat_ld<NL>(AY, dy, cb * bl.K + k, rb * bl.K + k));
+    }
+  const MatDesc db = BT.d[j];
+  Mw<NL> by = mw::zero<NL>();
+  for(int n = 0; n < N; ++n)
+    by = mw::fma(mat_ld<NL>(BT, db, n, p), mw::load<NL>(y, n), by);
+  mw::store<NL>(d, (size_t)bl.voff + p, mw::sub(acc, by));
+}
+
+// result = sum_p a[p] A_p (+/- addend)   (constraint_matrix_weighted_sum.cxx:14-66)
+// out batch is indexed 2j+parity.  addend_sign: 0 none, +1 add, -1 subtract.
+template <int NL>
+__global__ void __launch_bounds__(WG) k_constraint_weighted_sum(Batch bases, mw::CPtr a, Batch out, Batch addend,
+                                                                int addend_sign, const BlockDesc *blk)
+{
+  const int q = blockIdx.y;
+  const BlockDesc bl = blk[q >> 1];
+  const MatDesc dout = out.d[q], dbs = bases.d[q];
+  const int n = dout.rows, rs = bl.rows[q & 1];
+  const int idx = blockIdx.x * WG + threadIdx.x;
+  if(idx >= n * n)
+    return;
+  const int I = idx % n, Jc = idx / n;
+  const int bi = I / rs, i = I % rs, bj = Jc / rs, jj = Jc % rs;
+  const int hi = bi > bj ? bi : bj, lo = bi > bj ? bj : bi;
+  const size_t voff = (size_t)bl.voff + (size_t)(hi * (hi + 1) / 2 + lo) * bl.K;
+  Mw<NL> acc = mw::zero<NL>();
+  for(int k = 0; k < bl.K; ++k)
+    {
+      const Mw<NL> t = mw::mul(mat_ld<NL>(bases, dbs, jj, k), mw::load<NL>(a, voff + k));
+      acc = mw::fma(mat_ld<NL>(bases, dbs, i, k), t, acc);
+    }
+  if(hi != lo)
+    acc = mw::mul_2exp(acc, -1);
+  if(addend_sign)
+    {
+      const Mw<NL> ad = mat_ld<NL>(addend, addend.d[q], I, Jc);
+      acc = addend_sign > 0 ? mw::add(acc, ad) : mw::sub(acc, ad);
+    }
+  mat_st<NL>(out, dout, I, Jc, acc);
+}
+
+// dx[p] = -dual_residues[p] - Tr(A_p Z)   (compute_schur_RHS.cxx:21-86)
+template <int NL>
+__global__ void __launch_bounds__(WG)
+  k_schur_rhs(Batch bases, Batch Z, mw::CPtr dres, mw::Ptr dx, const BlockDesc *blk)
+{
+  const int j = blockIdx.y;
+  const BlockDesc bl = blk[j];
+  const int p = blockIdx.x * WG + threadIdx.x;
+  if(p >= bl.P)
+    return;
+  int cb, rb, k;
+  decode_p(p, bl.K, cb, rb, k);
+  Mw<NL> acc = mw::neg(mw::load<NL>(dres, (size_t)bl.voff + p));
+  for(int b = 0; b < 2; ++b)
+    {
+      const int rs = bl.rows[b];
+      const MatDesc dz = Z.d[2 * j + b], dbs = bases.d[2 * j + b];
+      Mw<NL> colsum = mw::zero<NL>();
+      for(int i = 0; i < rs; ++i)
+        {
+          Mw<NL> zq = mw::zero<NL>();
+          for(int l = 0; l < rs; ++l)
+            zq = mw::fma(mat_ld<NL>(Z, dz, rb * rs + i, cb * rs + l), mat_ld<NL>(bases, dbs, l, k), zq);
+          colsum = mw::fma(zq, mat_ld<NL>(bases, dbs, i, k), colsum);
+        }
+      acc = mw::sub(acc, colsum);
+    }
+  mw::store<NL>(dx, (size_t)bl.voff + p, acc);
+}
+
+// part[j*N + n] = sum_p MT_j(n,p) * v_j[p]  (square: MT^2) — per-block partials of
+// B^T x (compute_primal_residues_and_error_p_b_Bx.cxx:26-28), P^T dx
+// (solve_schur_complement_equation.cxx:33-35) and the column norms^2 of P
+// (Matrix_Normalizer.cxx:75-91).  One lane per (block, n); loads are coalesced in n.
+template <int NL, bool SQUARE>
+__global__ void __launch_bounds__(WG) k_gemv_t_partial(Batch MT, mw::CPtr v, mw::Ptr part, const BlockDesc *blk, int N)
+{
+  const int j = blockIdx.y;
+  const BlockDesc bl = blk[j];
+  const int n = blockIdx.x * WG + threadIdx.x;
+  if(n >= N)
+    return;
+  const MatDesc dm = MT.d[j];
+  Mw<NL> acc = mw::zero<NL>();
+  for(int p = 0; p < bl.P; ++p)
+    {
+      const Mw<NL> a = mat_ld<NL>(MT, dm, n, p);
+      acc = SQUARE ? mw::fma(a, a, acc) : mw::fma(a, mw::load<NL>(v, (size_t)bl.voff + p), acc);
+    }
+  mw::store<NL>(part, (size_t)j * N + n, acc);
+}
+// out[n] = (base ? base[n] : 0) + sign * sum_j part[j*N+n]
+template <int NL>
+__global__ void __launch_bounds__(WG) k_sum_partials(mw::CPtr part, int J, int N, mw::CPtr base, int has_base, int sign, mw::Ptr out)
+{
+  const int n = blockIdx.x * WG + threadIdx.x;
+  if(n >= N)
+    return;
+  Mw<NL> acc = mw::zero<NL>();
+  for(int j = 0; j < J; ++j)
+    acc = mw::add(acc, mw::load<NL>(part, (size_t)j * N + n));
+  if(sign < 0)
+    acc = mw::neg(acc);
+  if(has_base)
+    acc = mw::add(mw::load<NL>(base, n), acc);
+  mw::store<NL>(out, n, acc);
+}
+// dx_j[p] += sum_n PT_j(n,p) dy[n]   (solve_schur_complement_equation.cxx:69-74)
+template <int NL>
+__global__ void __launch_bounds__(WG) k_gemv_n_add(Batch PT, mw::CPtr dy, mw::Ptr dx, const BlockDesc *blk, int N)
+{
+  const int j = blockIdx.y;
+  const BlockDesc bl = blk[j];
+  const int p = blockIdx.x * WG + threadIdx.x;
+  if(p >= bl.P)
+    return;
+  const MatDesc dm = PT.d[j];
+  Mw<NL> acc = mw::load<NL>(dx, (size_t)bl.voff + p);
+  for(int n = 0; n < N; ++n)
+    acc = mw::fma(mat_ld<NL>(PT, dm, n, p), mw::load<NL>(dy, n), acc);
+  mw::store<NL>(dx, (size_t)bl.voff + p, acc);
+}
+
+// ---------------------------------------------------------------------------
+// Q = P^T P in fixed point  (the reference's bigint_syrk: Matrix_Normalizer.cxx:
+// 174-192 normalise-and-shift, bigint_syrk_blas.cxx:183-302 exact integer syrk,
+// Matrix_Normalizer.cxx:245-264 restore).  After column normalisation |P'| <= 1, so
+// P' * 2^FXB is an FX-limb integer plus sign; the product of two of them is
+// accumulated exactly in a (2FX+2)-limb two's-complement integer — no alignment,
+// no normalisation inside the hot loop, just v_mad_u64_u32 + carry.
+// ---------------------------------------------------------------------------
+// fx[idx] = trunc(PT[idx] * inv_norm[idx % N] * 2^(32 FX));  plane 0 of fx = sign.
+template <int NL, int FX>
+__global__ void __launch_bounds__(WG) k_normalize_fx(mw::CPtr PT, size_t count, int N, mw::CPtr inv_norm, uint32_t *fx, size_t fx_stride)
+{
+  for(size_t idx = (size_t)blockIdx.x * WG + threadIdx.x; idx < count; idx += (size_t)gridDim.x * WG)
+    {
+      const Mw<NL> t = mw::mul(mw::load<NL>(PT, idx), mw::load<NL>(inv_norm, idx % N));
+      uint32_t w[NL];
+      bool sat = false;
+      if(mw::is_zero(t))
+        {
+#pragma unroll
+          for(int i = 0; i < NL; ++i)
+            w[i] = 0;
+        }
+      else
+        {
+#pragma unroll
+          for(int i = 0; i < NL; ++i)
+            w[i] = t.m[i];
+          // integer = M * 2^(e + 32FX - 32NL): shift right by s
+          const int s = 32 * NL - 32 * FX - t.e;
+          if(t.e >= 1)
+            sat = true; // |t| >= 1 (only t == 1 up to rounding): clamp to 2^(32FX)-1
+          else if(s >= 32 * NL)
+            {
+#pragma unroll
+              for(int i = 0; i < NL; ++i)
+                w[i] = 0;
+            }
+          else
+            {
+              mw::shr_limbs<NL>(w, (uint32_t)s >> 5);
+              mw::shr_bits<NL>(w, (uint32_t)s & 31u);
+            }
+        }
+      bool nz = false;
+#pragma unroll
+      for(int i = 0; i < FX; ++i)
+        {
+          const uint32_t v = sat ? 0xffffffffu : w[i];
+          nz = nz || v != 0;
+          fx[(size_t)(i + 1) * fx_stride + idx] = v;
+        }
+      fx[idx] = (nz && t.neg) ? 1u : 0u;
+    }
+}
+
+// acc(i,j) (i >= j, tiles of 16x16) = sum_r fx(r,i) * fx(r,j), rows r in
+// [row0, row0+nrows).  fx element (r,n) at r*N + n.  acc element (i,j) at i + j*N in
+// a (2FX+2)-plane limb-major two's-complement array.  Row chunks of RB rows are
+// staged through LDS (limb-major, so lanes of a wavefront hit distinct banks for
+// the i operand and broadcast the j operand).  accumulate != 0 adds to acc.
+template <int FX, int RB>
+__global__ void __launch_bounds__(WG)
+  k_syrk_fx(const uint32_t *fx, size_t fx_stride, size_t row0, size_t nrows, int N, uint32_t *acc, size_t acc_stride, int accumulate)
+{
+  constexpr int W = 2 * FX + 2;
+  const int tiles = (N + 15) / 16;
+  int tile = blockIdx.x;
+  if(tile >= tiles * (tiles + 1) / 2)
+    return;
+  int ti = 0;
+  while((ti + 1) * (ti + 2) / 2 <= tile)
+    ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
+  const int i = ti * 16 + li, j = tj * 16 + lj;
+  __shared__ uint32_t sa[(FX + 1) * RB * 16];
+  __shared__ uint32_t sb[(FX + 1) * RB * 16];
+  uint32_t a_acc[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    a_acc[k] = 0;
+  for(size_t r0 = 0; r0 < nrows; r0 += RB)
+    {
+      // stage: (FX+1) planes x RB rows x 16 columns for each operand
+      for(int e = threadIdx.x; e < (FX + 1) * RB * 16; e += WG)
+        {
+          const int col = e & 15, rr = (e >> 4) % RB, pl = (e >> 4) / RB;
+          const size_t r = r0 + rr;
+          const int ca = ti * 16 + col, cb = tj * 16 + col;
+          const bool okr = r < nrows;
+          sa[e] = (okr && ca < N) ? fx[(size_t)pl * fx_stride + (row0 + r) * (size_t)N + ca] : 0u;
+          sb[e] = (okr && cb < N) ? fx[(size_t)pl * fx_stride + (row0 + r) * (size_t)N + cb] : 0u;
+        }
+      __syncthreads();
+#pragma unroll 1
+      for(int rr = 0; rr < RB; ++rr)
+        {
+          uint32_t a[FX], b[FX];
+#pragma unroll
+          for(int l = 0; l < FX; ++l)
+            {
+              a[l] = sa[((l + 1) * RB + rr) * 16 + li];
+              b[l] = sb[((l + 1) * RB + rr) * 16 + lj];
+            }
+          const uint32_t sgn = sa[rr * 16 + li] ^ sb[rr * 16 + lj];
+          const uint32_t mask = 0u - sgn; // 0 or ~0
+          // product scanning; each finished column limb goes straight into acc as
+          // (limb ^ mask) with the two's-complement +1 folded into the first carry
+          uint64_t lo = 0;
+          uint32_t hi = 0;
+          uint32_t carry = sgn;
+#pragma unroll
+          for(int k = 0; k < 2 * FX - 1; ++k)
+            {
+#pragma unroll
+              for(int ii = (k - (FX - 1) > 0 ? k - (FX - 1) : 0); ii <= (k < FX - 1 ? k : FX - 1); ++ii)
+                MW_MAC(lo, hi, a[ii], b[k - ii]);
+              const uint32_t limb = (uint32_t)lo ^ mask;
+              lo = (lo >> 32) | ((uint64_t)hi << 32);
+              hi = 0;
+              const uint64_t s = (uint64_t)a_acc[k] + limb + carry;
+              a_acc[k] = (uint32_t)s;
+              carry = (uint32_t)(s >> 32);
+            }
+          {
+            const uint32_t limb = (uint32_t)lo ^ mask;
+            const uint64_t s = (uint64_t)a_acc[2 * FX - 1] + limb + carry;
+            a_acc[2 * FX - 1] = (uint32_t)s;
+            carry = (uint32_t)(s >> 32);
+          }
+#pragma unroll
+          for(int k = 2 * FX; k < W; ++k)
+            {
+              const uint64_t s = (uint64_t)a_acc[k] + mask + carry;
+              a_acc[k] = (uint32_t)s;
+              carry = (uint32_t)(s >> 32);
+            }
+        }
+      __syncthreads();
+    }
+  if(i < N && j <= i)
+    {
+      const size_t o = (size_t)i + (size_t)j * N;
+      uint32_t carry = 0;
+#pragma unroll
+      for(int k = 0; k < W; ++k)
+        {
+          uint32_t v = a_acc[k];
+          if(accumulate)
+            {
+              const uint64_t s = (uint64_t)acc[(size_t)k * acc_stride + o] + v + carry;
+              v = (uint32_t)s;
+              carry = (uint32_t)(s >> 32);
+            }
+          acc[(size_t)k * acc_stride + o] = v;
+        }
+    }
+}
+
+// Q(i,j) = (acc(i,j) / 2^(64 FX)) * norm_i * norm_j for i >= j; checks the diagonal
+// (check_normalized_Q_diagonal, compute_Q.cxx:65-91): |Q'_ii - 1| < 2^(-16 FX).
+template <int NL, int FX>
+__global__ void __launch_bounds__(WG)
+  k_restore_Q(const uint32_t *acc, size_t acc_stride, int N, mw::CPtr norms, mw::Ptr Q, int *diag_fail)
+{
+  constexpr int W = 2 * FX + 2;
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)N * N)
+    return;
+  const int i = (int)(idx % N), j = (int)(idx / N);
+  if(i < j)
+    {
+      mw::store<NL>(Q, idx, mw::zero<NL>());
+      return;
+    }
+  uint32_t w[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    w[k] = acc[(size_t)k * acc_stride + idx];
+  const uint32_t negative = w[W - 1] >> 31;
+  if(negative)
+    {
+      uint32_t carry = 1;
+#pragma unroll
+      for(int k = 0; k < W; ++k)
+        {
+          const uint64_t s = (uint64_t)(~w[k]) + carry;
+          w[k] = (uint32_t)s;
+          carry = (uint32_t)(s >> 32);
+        }
+    }
+  // magnitude w as a W-limb integer; value = w / 2^(64FX) = (w / 2^(32W)) * 2^(32W - 64FX)
+  uint32_t zl = 0, topw = 0;
+  bool found = false;
+#pragma unroll
+  for(int k = W - 1; k >= 0; --k)
+    {
+      const bool nz = w[k] != 0;
+      if(!found && nz)
+        topw = w[k];
+      if(!found && !nz)
+        zl += 1;
+      found = found || nz;
+    }
+  Mw<NL> v = mw::zero<NL>();
+  if(found)
+    {
+      const uint32_t c = mw::clz32(topw);
+      mw::shl_limbs<W>(w, zl);
+      mw::shl_bits<W>(w, c);
+#pragma unroll
+      for(int k = 0; k < NL; ++k)
+        v.m[k] = (W - NL + k >= 0) ? w[W - NL + k >= 0 ? W - NL + k : 0] : 0u;
+      v.e = 32 * W - 64 * FX - (int32_t)(32u * zl + c);
+      v.neg = negative;
+    }
+  const Mw<NL> ni = mw::load<NL>(norms, i);
+  if(i == j && !mw::is_zero(ni))
+    {
+      const Mw<NL> diff = mw::abs(mw::sub(v, mw::from_u32<NL>(1)));
+      if(!mw::is_zero(diff) && diff.e > -16 * FX)
+        atomicMax(diag_fail, i + 1);
+    }
+  v = mw::mul(mw::mul(v, ni), mw::load<NL>(norms, j));
+  mw::store<NL>(Q, idx, v);
+}
+
+// ---------------------------------------------------------------------------
+// Smallest eigenvalue of a batch of symmetric matrices: cyclic Jacobi with the
+// round-robin parallel ordering, one workgroup per matrix, in place.
+// Replaces El::HermitianEig + El::Min at min_eigenvalue.cxx:8-33.
+// lam[q] = lambda_min (zero-size matrices write +huge so they never win the MIN).
+// ---------------------------------------------------------------------------
+constexpr int JACOBI_MAX_HALF = 128; // supports n <= 256
+template <int NL> __global__ void __launch_bounds__(WG) k_jacobi_min_eig(Batch A, mw::Ptr lam, int max_sweeps)
+{
+  const int q = blockIdx.x;
+  const MatDesc d = A.d[q];
+  const int n = d.rows, t = threadIdx.x;
+  if(n == 0)
+    {
+      if(t == 0)
+        {
+          Mw<NL> big = mw::from_u32<NL>(1);
+          big.e = 1 << 28;
+          mw::store<NL>(lam, q, big);
+        }
+      return;
+    }
+  __shared__ Mw<NL> s_c[JACOBI_MAX_HALF], s_s[JACOBI_MAX_HALF];
+  __shared__ int s_p[JACOBI_MAX_HALF], s_q[JACOBI_MAX_HALF], s_rot;
+  const int ne = (n + 1) & ~1, half = ne / 2;
+  for(int sweep = 0; sweep < max_sweeps && n > 1; ++sweep)
+    {
+      if(t == 0)
+        s_rot = 0;
+      __syncthreads();
+      for(int rd = 0; rd < ne - 1; ++rd)
+        {
+          // phase A: rotation parameters for the pairs of this round
+          for(int k = t; k < half; k += WG)
+            {
+              int pa, pb;
+              if(k == 0)
+                {
+                  pa = ne - 1;
+                  pb = rd;
+                }
+              else
+                {
+                  pa = (rd + k) % (ne - 1);
+                  pb = (rd - k + (ne - 1)) % (ne - 1);
+                }
+              int p = pa < pb ? pa : pb, qq = pa < pb ? pb : pa;
+              Mw<NL> c = mw::from_u32<NL>(1), s = mw::zero<NL>();
+              if(qq >= n)
+                p = -1; // dummy player of an odd-sized matrix
+              else
+                {
+                  const Mw<NL> apq = mat_ld<NL>(A, d, p, qq);
+                  const Mw<NL> app = mat_ld<NL>(A, d, p, p), aqq = mat_ld<NL>(A, d, qq, qq);
+                  // negligible when |apq| < 2^-(32NL-6) sqrt(|app aqq|)
+                  bool rotate = !mw::is_zero(apq);
+                  if(rotate && !mw::is_zero(app) && !mw::is_zero(aqq))
+                    rotate = 2 * apq.e > app.e + aqq.e - 2 * (32 * NL - 6);
+                  if(rotate)
+                    {
+                      const Mw<NL> one = mw::from_u32<NL>(1);
+                      const Mw<NL> theta = mw::div(mw::sub(aqq, app), mw::mul_2exp(apq, 1));
+                      Mw<NL> tt;
+                      if(mw::is_zero(theta))
+                        tt = one;
+                      else
+                        {
+                          const Mw<NL> rt = mw::sqrt(mw::add(mw::mul(theta, theta), one));
+                          tt = mw::rcp(mw::add(mw::abs(theta), rt));
+                          tt.neg = theta.neg;
+                        }
+                      c = mw::rsqrt(mw::add(mw::mul(tt, tt), one));
+                      s = mw::mul(tt, c);
+                      s_rot = 1;
+                    }
+                  else
+                    p = -1;
+                }
+              s_p[k] = p;
+              s_q[k] = qq;
+              s_c[k] = c;
+              s_s[k] = s;
+            }
+          __syncthreads();
+          // phase B: A <- A J (columns p,q)
+          for(int idx = t; idx < half * n; idx += WG)
+            {
+              const int k = idx / n, r = idx % n, p = s_p[k], qq = s_q[k];
+              if(p < 0)
+                continue;
+              const Mw<NL> c = s_c[k], s = s_s[k];
+              const Mw<NL> x = mat_ld<NL>(A, d, r, p), y = mat_ld<NL>(A, d, r, qq);
+              mat_st<NL>(A, d, r, p, mw::sub(mw::mul(c, x), mw::mul(s, y)));
+              mat_st<NL>(A, d, r, qq, mw::add(mw::mul(s, x), mw::mul(c, y)));
+            }
+          __syncthreads();
+          // phase C: A <- J^T A (rows p,q)
+          for(int idx = t; idx < half * n; idx += WG)
+            {
+              const int k = idx / n, cc = idx % n, p = s_p[k], qq = s_q[k];
+              if(p < 0)
+                continue;
+              const Mw<NL> c = s_c[k], s = s_s[k];
+              const Mw<NL> x = mat_ld<NL>(A, d, p, cc), y = mat_ld<NL>(A, d, qq, cc);
+              mat_st<NL>(A, d, p, cc, mw::sub(mw::mul(c, x), mw::mul(s, y)));
+              mat_st<NL>(A, d, qq, cc, mw::add(mw::mul(s, x), mw::mul(c, y)));
+            }
+          __syncthreads();
+        }
+      const int rot = s_rot;
+      __syncthreads();
+      if(!rot)
+        break;
+    }
+  if(t == 0)
+    {
+      Mw<NL> mn = mat_ld<NL>(A, d, 0, 0);
+      for(int i = 1; i < n; ++i)
+        mn = mw::min(mn, mat_ld<NL>(A, d, i, i));
+      mw::store<NL>(lam, q, mn);
+    }
+}
+
+// (max diag / min diag) per matrix: cholesky_condition_number.hxx:8-37 without the
+// final square (done on the host for the winner only).
+template <int NL> __global__ void __launch_bounds__(WG) k_diag_ratio(Batch L, mw::Ptr out, size_t out_off)
+{
+  const int q = blockIdx.x * WG + threadIdx.x;
+  if(q >= L.count)
+    return;
+  const MatDesc d = L.d[q];
+  Mw<NL> r = mw::zero<NL>();
+  if(d.rows > 0)
+    {
+      Mw<NL> mx = mat_ld<NL>(L, d, 0, 0), mn = mx;
+      for(int i = 1; i < d.rows; ++i)
+        {
+          const Mw<NL> v = mat_ld<NL>(L, d, i, i);
+          mx = mw::max(mx, v);
+          mn = mw::min(mn, v);
+        }
+      r = mw::div(mx, mn);
+    }
+  mw::store<NL>(out, out_off + q, r);
+}
+
+// ---- multi-GPU exchange images ----------------------------------------------
+// 32-bit two's-complement limbs widened to u64 lanes so that an integer SUM
+// all-reduce (RCCL ncclSum on uint64) adds the partial Q' of every GPU exactly;
+// k_narrow_carry propagates the deferred carries afterwards.  
+template <int UNUSED = 0> __global__ void __launch_bounds__(WG) k_widen_u64(const uint32_t *in, size_t count, unsigned long long *out)
+{
+  for(size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < count; i += (size_t)gridDim.x * WG)
+    out[i] = in[i];
+}
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(WG)
+  k_narrow_carry(const unsigned long long *in, size_t elems, int planes, uint32_t *out)
+{
+  for(size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < elems; i += (size_t)gridDim.x * WG)
+    {
+      unsigned long long carry = 0;
+      for(int k = 0; k < planes; ++k)
+        {
+          const unsigned long long s = in[(size_t)k * elems + i] + carry;
+          out[(size_t)k * elems + i] = (uint32_t)s;
+          carry = s >> 32;
+        }
+    }
+}
+} // namespace sdpb

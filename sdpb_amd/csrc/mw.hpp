@@ -1,0 +1,545 @@
+// mw.hpp — fixed-width multi-word floating point for gfx950 (and the host side of
+// the same library).  This is the number format that replaces El::BigFloat
+// (GMP mpf; reference: src/sdpb_util/Environment.cxx:29-36 sets its precision) on
+// the device.
+//
+//   value = (-1)^neg * (M / 2^(32*NL)) * 2^e ,   M = sum m[i] 2^(32 i)
+//
+// M is bit-normalised (top bit of m[NL-1] set) unless the value is zero, so the
+// precision is a constant 32*NL bits (GMP's mpf is limb-normalised and fluctuates
+// between 64*(l-1)+1 and 64*(l+1) bits).  All operations truncate toward zero in
+// magnitude like mpf.  Limbs are 32-bit because the CDNA4 integer multiplier is
+// v_mad_u64_u32 (32x32+64 -> 64, quarter rate); every limb loop is fully unrolled
+// with compile-time indices so mantissas live in VGPRs, never in scratch.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define MW_HD __host__ __device__ __forceinline__
+#else
+#define MW_HD inline __attribute__((always_inline))
+#endif
+
+namespace mw
+{
+constexpr int32_t EZERO = -(1 << 29); // exponent tag of the value zero
+constexpr uint32_t EBIAS = 1u << 30;  // header = sign<<31 | (e + EBIAS)
+
+template <int NL> struct Mw
+{
+  uint32_t m[NL];
+  int32_t e;
+  uint32_t neg;
+};
+
+// ---- 96-bit column accumulator for product scanning ------------------------
+// acc(lo:64, hi:32) += a*b
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MW_MAC(lo, hi, a, b)                                                   \
+  asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, " \
+               "0, %1, vcc"                                                    \
+               : "+v"(lo), "+v"(hi)                                            \
+               : "v"(a), "v"(b)                                                \
+               : "vcc")
+#else
+#define MW_MAC(lo, hi, a, b)                                                   \
+  do                                                                           \
+    {                                                                          \
+      const uint64_t p__ = (uint64_t)(a) * (uint64_t)(b);                      \
+      lo += p__;                                                               \
+      hi += (lo < p__) ? 1u : 0u;                                              \
+    }                                                                          \
+  while(0)
+#endif
+
+MW_HD uint32_t clz32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__clz((int)x);
+#else
+  return x ? (uint32_t)__builtin_clz(x) : 32u;
+#endif
+}
+// (hi:lo) << c, upper word; 0 <= c <= 31
+MW_HD uint32_t funnel_l(uint32_t hi, uint32_t lo, uint32_t c)
+{
+  return c ? ((hi << c) | (lo >> (32 - c))) : hi;
+}
+// (hi:lo) >> c, lower word; 0 <= c <= 31
+MW_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t c)
+{
+  return c ? ((lo >> c) | (hi << (32 - c))) : lo;
+}
+
+template <int NL> MW_HD Mw<NL> zero()
+{
+  Mw<NL> r;
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    r.m[i] = 0;
+  r.e = EZERO;
+  r.neg = 0;
+  return r;
+}
+template <int NL> MW_HD bool is_zero(const Mw<NL> &a) { return a.e == EZERO; }
+
+template <int NL> MW_HD Mw<NL> neg(Mw<NL> a)
+{
+  if(a.e != EZERO)
+    a.neg ^= 1u;
+  return a;
+}
+template <int NL> MW_HD Mw<NL> abs(Mw<NL> a)
+{
+  a.neg = 0;
+  return a;
+}
+// a * 2^k
+template <int NL> MW_HD Mw<NL> mul_2exp(Mw<NL> a, int k)
+{
+  if(a.e != EZERO)
+    a.e += k;
+  return a;
+}
+
+// small non-negative integer
+template <int NL> MW_HD Mw<NL> from_u32(uint32_t v)
+{
+  Mw<NL> r = zero<NL>();
+  if(v == 0)
+    return r;
+  const uint32_t c = clz32(v);
+  r.m[NL - 1] = v << c;
+  r.e = 32 - (int)c;
+  return r;
+}
+template <int NL> MW_HD Mw<NL> from_i32(int32_t v)
+{
+  Mw<NL> r = from_u32<NL>(v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v);
+  r.neg = v < 0;
+  return r;
+}
+
+// from a finite double (exact)
+template <int NL> MW_HD Mw<NL> from_double(double d)
+{
+  Mw<NL> r = zero<NL>();
+  if(d == 0.0)
+    return r;
+  union
+  {
+    double d;
+    uint64_t u;
+  } cv;
+  cv.d = d;
+  const uint64_t bits = cv.u;
+  r.neg = (uint32_t)(bits >> 63);
+  int ex = (int)((bits >> 52) & 0x7ff);
+  uint64_t man = bits & 0xfffffffffffffull;
+  if(ex == 0)
+    ex = 1; // subnormal
+  else
+    man |= 1ull << 52;
+  // value = man * 2^(ex-1075); normalise man to bit 63
+  int lz = 0;
+  while(!(man >> 63))
+    {
+      man <<= 1;
+      ++lz;
+    }
+  r.m[NL - 1] = (uint32_t)(man >> 32);
+  if(NL > 1)
+    r.m[NL > 1 ? NL - 2 : 0] = (uint32_t)man;
+  r.e = ex - 1075 + 64 - lz;
+  return r;
+}
+// nearest-ish double (truncated); no overflow handling beyond inf/0
+template <int NL> MW_HD double to_double(const Mw<NL> &a)
+{
+  if(a.e == EZERO)
+    return 0.0;
+  uint64_t top = ((uint64_t)a.m[NL - 1] << 32) | (NL > 1 ? a.m[NL > 1 ? NL - 2 : 0] : 0u);
+  // top has bit 63 set; value = top/2^64 * 2^e
+  int e = a.e;
+  if(e > 1023)
+    return a.neg ? -1e308 * 10 : 1e308 * 10;
+  if(e < -1020)
+    return 0.0;
+  union
+  {
+    double d;
+    uint64_t u;
+  } cv;
+  cv.u = ((uint64_t)(e - 1 + 1023) << 52) | ((top >> 11) & 0xfffffffffffffull);
+  return a.neg ? -cv.d : cv.d;
+}
+
+// compare magnitudes: -1,0,1
+template <int NL> MW_HD int cmp_abs(const Mw<NL> &a, const Mw<NL> &b)
+{
+  if(a.e != b.e)
+    return a.e < b.e ? -1 : 1;
+  int r = 0;
+#pragma unroll
+  for(int i = NL - 1; i >= 0; --i)
+    if(r == 0 && a.m[i] != b.m[i])
+      r = a.m[i] < b.m[i] ? -1 : 1;
+  return r;
+}
+template <int NL> MW_HD int cmp(const Mw<NL> &a, const Mw<NL> &b)
+{
+  const bool az = a.e == EZERO, bz = b.e == EZERO;
+  if(az && bz)
+    return 0;
+  if(az)
+    return b.neg ? 1 : -1;
+  if(bz)
+    return a.neg ? -1 : 1;
+  if(a.neg != b.neg)
+    return a.neg ? -1 : 1;
+  const int c = cmp_abs(a, b);
+  return a.neg ? -c : c;
+}
+template <int NL> MW_HD bool lt(const Mw<NL> &a, const Mw<NL> &b) { return cmp(a, b) < 0; }
+template <int NL> MW_HD bool gt(const Mw<NL> &a, const Mw<NL> &b) { return cmp(a, b) > 0; }
+template <int NL> MW_HD Mw<NL> max(const Mw<NL> &a, const Mw<NL> &b) { return cmp(a, b) < 0 ? b : a; }
+template <int NL> MW_HD Mw<NL> min(const Mw<NL> &a, const Mw<NL> &b) { return cmp(a, b) < 0 ? a : b; }
+
+// ---- multiplication: short product (top NL limbs + one guard column) -------
+// The dropped low columns contribute < NL * 2^-32 ulp, far inside mpf's own
+// 1-ulp truncation.
+template <int NL> MW_HD Mw<NL> mul(const Mw<NL> &a, const Mw<NL> &b)
+{
+  if(a.e == EZERO || b.e == EZERO)
+    return zero<NL>();
+  uint32_t r[NL + 1]; // r[0] = product limb NL-1 (guard for the 1-bit shift), r[k] = limb NL-1+k
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+  // guard column k = NL-2: only its carry is kept
+  if(NL >= 2)
+    {
+#pragma unroll
+      for(int i = 0; i <= NL - 2; ++i)
+        MW_MAC(lo, hi, a.m[i], b.m[NL - 2 - i]);
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+#pragma unroll
+  for(int k = NL - 1; k <= 2 * NL - 2; ++k)
+    {
+#pragma unroll
+      for(int i = (k - (NL - 1) > 0 ? k - (NL - 1) : 0); i <= (k < NL - 1 ? k : NL - 1); ++i)
+        MW_MAC(lo, hi, a.m[i], b.m[k - i]);
+      r[k - (NL - 1)] = (uint32_t)lo;
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+  // top limb (product limb 2NL-1) = remaining lo
+  Mw<NL> out;
+  const uint32_t top = (uint32_t)lo;
+  out.neg = a.neg ^ b.neg;
+  if(top >> 31)
+    {
+#pragma unroll
+      for(int i = 0; i < NL - 1; ++i)
+        out.m[i] = r[i + 1];
+      out.m[NL - 1] = top;
+      out.e = a.e + b.e;
+    }
+  else
+    {
+#pragma unroll
+      for(int i = 0; i < NL - 1; ++i)
+        out.m[i] = (r[i + 1] << 1) | (r[i] >> 31);
+      out.m[NL - 1] = (top << 1) | (r[NL - 1] >> 31);
+      out.e = a.e + b.e - 1;
+    }
+  return out;
+}
+template <int NL> MW_HD Mw<NL> sqr(const Mw<NL> &a) { return mul(a, a); }
+
+// ---- addition / subtraction ------------------------------------------------
+// helpers on NL+1-limb working arrays (index NL = most significant)
+template <int W> MW_HD void shr_limbs(uint32_t (&x)[W], uint32_t q)
+{
+#pragma unroll
+  for(int s = 1; s < W; s <<= 1)
+    {
+      const bool on = (q & (uint32_t)s) != 0;
+#pragma unroll
+      for(int i = 0; i < W; ++i)
+        {
+          const uint32_t from = (i + s < W) ? x[i + s < W ? i + s : 0] : 0u;
+          x[i] = on ? from : x[i];
+        }
+    }
+}
+template <int W> MW_HD void shl_limbs(uint32_t (&x)[W], uint32_t q)
+{
+#pragma unroll
+  for(int s = 1; s < W; s <<= 1)
+    {
+      const bool on = (q & (uint32_t)s) != 0;
+#pragma unroll
+      for(int i = W - 1; i >= 0; --i)
+        {
+          const uint32_t from = (i - s >= 0) ? x[i - s >= 0 ? i - s : 0] : 0u;
+          x[i] = on ? from : x[i];
+        }
+    }
+}
+template <int W> MW_HD void shr_bits(uint32_t (&x)[W], uint32_t c)
+{
+#pragma unroll
+  for(int i = 0; i < W - 1; ++i)
+    x[i] = funnel_r(x[i + 1], x[i], c);
+  x[W - 1] = x[W - 1] >> c; // c in 0..31
+}
+template <int W> MW_HD void shl_bits(uint32_t (&x)[W], uint32_t c)
+{
+#pragma unroll
+  for(int i = W - 1; i >= 1; --i)
+    x[i] = funnel_l(x[i], x[i - 1], c);
+  x[0] = x[0] << c;
+}
+
+// Normalise a (NL+1)-limb magnitude w (value w/2^(32(NL+1)) * 2^e) into r
+template <int NL> MW_HD Mw<NL> normalize_w(uint32_t (&w)[NL + 1], int32_t e, uint32_t neg)
+{
+  // leading zero limbs
+  uint32_t zl = 0;
+  bool found = false;
+  uint32_t topw = 0;
+#pragma unroll
+  for(int i = NL; i >= 0; --i)
+    {
+      const bool nz = w[i] != 0;
+      if(!found && nz)
+        topw = w[i];
+      if(!found && !nz)
+        zl += 1;
+      found = found || nz;
+    }
+  if(!found)
+    return zero<NL>();
+  const uint32_t c = clz32(topw);
+  shl_limbs<NL + 1>(w, zl);
+  shl_bits<NL + 1>(w, c);
+  Mw<NL> r;
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    r.m[i] = w[i + 1];
+  r.e = e - (int32_t)(32u * zl + c);
+  r.neg = neg;
+  return r;
+}
+
+template <int NL> MW_HD Mw<NL> add(const Mw<NL> &a_in, const Mw<NL> &b_in)
+{
+  if(a_in.e == EZERO)
+    return b_in;
+  if(b_in.e == EZERO)
+    return a_in;
+  // big = larger magnitude
+  const bool swap = cmp_abs(a_in, b_in) < 0;
+  const Mw<NL> &a = swap ? b_in : a_in;
+  const Mw<NL> &b = swap ? a_in : b_in;
+  const uint32_t d = (uint32_t)(a.e - b.e);
+  if(d >= 32u * (NL + 1))
+    return a;
+  uint32_t x[NL + 1], y[NL + 1];
+  x[0] = 0;
+  y[0] = 0;
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    {
+      x[i + 1] = a.m[i];
+      y[i + 1] = b.m[i];
+    }
+  shr_limbs<NL + 1>(y, d >> 5);
+  shr_bits<NL + 1>(y, d & 31u);
+  if(a.neg == b.neg)
+    {
+      uint32_t carry = 0;
+#pragma unroll
+      for(int i = 0; i <= NL; ++i)
+        {
+          const uint64_t s = (uint64_t)x[i] + y[i] + carry;
+          x[i] = (uint32_t)s;
+          carry = (uint32_t)(s >> 32);
+        }
+      Mw<NL> r;
+      r.neg = a.neg;
+      if(carry)
+        {
+#pragma unroll
+          for(int i = 0; i < NL - 1; ++i)
+            r.m[i] = (x[i + 1] >> 1) | (x[i + 2] << 31);
+          r.m[NL - 1] = (x[NL] >> 1) | 0x80000000u;
+          r.e = a.e + 1;
+        }
+      else
+        {
+#pragma unroll
+          for(int i = 0; i < NL; ++i)
+            r.m[i] = x[i + 1];
+          r.e = a.e;
+        }
+      return r;
+    }
+  // |a| >= |b| : x - y >= 0
+  uint32_t borrow = 0;
+#pragma unroll
+  for(int i = 0; i <= NL; ++i)
+    {
+      const uint64_t s = (uint64_t)x[i] - y[i] - borrow;
+      x[i] = (uint32_t)s;
+      borrow = (uint32_t)(s >> 63);
+    }
+  return normalize_w<NL>(x, a.e, a.neg);
+}
+template <int NL> MW_HD Mw<NL> sub(const Mw<NL> &a, const Mw<NL> &b) { return add(a, neg(b)); }
+
+// acc + a*b, acc - a*b (two roundings, like mpf's `acc += a*b`)
+template <int NL> MW_HD Mw<NL> fma(const Mw<NL> &a, const Mw<NL> &b, const Mw<NL> &acc)
+{
+  return add(acc, mul(a, b));
+}
+template <int NL> MW_HD Mw<NL> fms(const Mw<NL> &a, const Mw<NL> &b, const Mw<NL> &acc)
+{
+  return add(acc, neg(mul(a, b)));
+}
+
+// ---- reciprocal, division, square root (Newton from a double seed) ---------
+template <int NL> constexpr int newton_iters()
+{
+  // seed ~ 2^-50 relative; each step squares the error
+  int bits = 50, it = 0;
+  while(bits < 32 * NL + 2)
+    {
+      bits = 2 * bits - 2;
+      ++it;
+    }
+  return it;
+}
+
+template <int NL> MW_HD Mw<NL> rcp(const Mw<NL> &a)
+{
+  // caller guarantees a != 0
+  Mw<NL> man = a;
+  man.e = 0;
+  man.neg = 0; // in [0.5,1)
+  Mw<NL> r = from_double<NL>(1.0 / to_double(man));
+  const Mw<NL> one = from_u32<NL>(1);
+#pragma unroll 1
+  for(int it = 0; it < newton_iters<NL>(); ++it)
+    {
+      // r += r*(1 - man*r)
+      const Mw<NL> t = sub(one, mul(man, r));
+      r = add(r, mul(r, t));
+    }
+  r.e -= a.e;
+  r.neg = a.neg;
+  return r;
+}
+template <int NL> MW_HD Mw<NL> div(const Mw<NL> &a, const Mw<NL> &b)
+{
+  if(a.e == EZERO)
+    return a;
+  // q = a*r, one correction step: q += r*(a - b*q)
+  const Mw<NL> r = rcp(b);
+  Mw<NL> q = mul(a, r);
+  const Mw<NL> rem = sub(a, mul(b, q));
+  return add(q, mul(r, rem));
+}
+
+// 1/sqrt(a), a > 0
+template <int NL> MW_HD Mw<NL> rsqrt(const Mw<NL> &a)
+{
+  Mw<NL> man = a;
+  int32_t e = a.e;
+  // make exponent even: man in [0.5,2)
+  const int odd = e & 1;
+  man.e = odd;
+  man.neg = 0;
+  e -= odd;
+  double seed = to_double(man);
+#if defined(__HIP_DEVICE_COMPILE__)
+  seed = 1.0 / ::sqrt(seed);
+#else
+  seed = 1.0 / __builtin_sqrt(seed);
+#endif
+  Mw<NL> r = from_double<NL>(seed);
+  const Mw<NL> three = from_u32<NL>(3);
+#pragma unroll 1
+  for(int it = 0; it < newton_iters<NL>(); ++it)
+    {
+      // r = r*(3 - man*r^2)/2
+      const Mw<NL> t = sub(three, mul(man, mul(r, r)));
+      r = mul_2exp(mul(r, t), -1);
+    }
+  r.e -= e / 2;
+  return r;
+}
+// sqrt(a), a >= 0 : s = a*r, one correction s += r*(a - s^2)/2
+template <int NL> MW_HD Mw<NL> sqrt(const Mw<NL> &a)
+{
+  if(a.e == EZERO)
+    return a;
+  const Mw<NL> r = rsqrt(a);
+  Mw<NL> s = mul(a, r);
+  const Mw<NL> rem = sub(a, mul(s, s));
+  return add(s, mul_2exp(mul(r, rem), -1));
+}
+
+// ---- global-memory layout: limb-major structure of arrays -------------------
+// plane 0 = header (sign<<31 | e+EBIAS, 0 for zero); plane 1+i = limb i.
+// A wavefront touching 64 consecutive elements issues one coalesced 256-B
+// transaction per plane.
+struct Ptr
+{
+  uint32_t *base;
+  size_t stride; // elements per plane
+};
+struct CPtr
+{
+  const uint32_t *base;
+  size_t stride;
+  CPtr() = default;
+  MW_HD CPtr(const uint32_t *b, size_t s) : base(b), stride(s) {}
+  MW_HD CPtr(const Ptr &p) : base(p.base), stride(p.stride) {}
+};
+MW_HD Ptr offset(Ptr p, size_t off) { return Ptr{p.base + off, p.stride}; }
+MW_HD CPtr offset(CPtr p, size_t off) { return CPtr(p.base + off, p.stride); }
+
+template <int NL> MW_HD Mw<NL> load(CPtr p, size_t i)
+{
+  Mw<NL> r;
+  const uint32_t h = p.base[i];
+#pragma unroll
+  for(int k = 0; k < NL; ++k)
+    r.m[k] = p.base[(size_t)(k + 1) * p.stride + i];
+  r.neg = h >> 31;
+  r.e = h ? (int32_t)((h & 0x7fffffffu) - EBIAS) : EZERO;
+  return r;
+}
+template <int NL> MW_HD Mw<NL> load(Ptr p, size_t i) { return load<NL>(CPtr(p), i); }
+template <int NL> MW_HD void store(Ptr p, size_t i, const Mw<NL> &a)
+{
+  const bool z = a.e == EZERO;
+  p.base[i] = z ? 0u : ((a.neg << 31) | (uint32_t)(a.e + (int32_t)EBIAS));
+#pragma unroll
+  for(int k = 0; k < NL; ++k)
+    p.base[(size_t)(k + 1) * p.stride + i] = z ? 0u : a.m[k];
+}
+MW_HD bool is_zero_at(CPtr p, size_t i) { return p.base[i] == 0; }
+
+// limbs for a requested --precision: 2*floor((p+127)/64), i.e. the same 64-bit
+// limb count l(p) GMP allocates for mpf, expressed in 32-bit limbs.
+inline int limbs_for_precision(int precision_bits)
+{
+  const int p = precision_bits < 53 ? 53 : precision_bits;
+  return 2 * ((p + 127) / 64);
+}
+} // namespace mw

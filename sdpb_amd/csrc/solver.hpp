@@ -1,0 +1,1380 @@
+// solver.hpp — host driver of the device-resident interior-point iteration.
+//
+// Mirrors the reference's SDP_Solver (src/sdp_solve/SDP_Solver.hxx:28-112): state
+// x, X, y, Y and the residues live in HBM for the whole run; iterate() is one pass
+// of the loop body of SDP_Solver::run (run/run.cxx:380-467) including
+// SDP_Solver::step (run/step/step.cxx:51-229).  Only a handful of scalars cross
+// PCIe per iteration.  There is no CPU compute path: every matrix operation is a
+// HIP kernel launch (kernels.hpp).
+#pragma once
+#include "kernels.hpp"
+#include "mw_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <utility>
+
+namespace sdpb
+{
+struct SolverError : std::runtime_error
+{
+  int code; // 1 = Cholesky not PD, 4 = bad argument (include/sdpb_hip.h)
+  SolverError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// Collective callbacks supplied by the caller (one process per GPU; the Python
+// launcher implements them with torch.distributed over RCCL, a C++ caller with RCCL
+// or MPI directly).  Buffers are device pointers owned by the library.
+struct Collectives
+{
+  // in-place SUM over ranks of `count` unsigned 64-bit integers
+  int (*allreduce_sum_u64)(void *user, void *dev_ptr, size_t count) = nullptr;
+  // gather `bytes` from every rank into recv (world*bytes), rank order
+  int (*allgather_bytes)(void *user, const void *dev_send, void *dev_recv, size_t bytes) = nullptr;
+  void *user = nullptr;
+};
+
+enum TerminateReason // SDP_Solver_Terminate_Reason.hxx
+{
+  NotTerminated = -1,
+  PrimalDualOptimal = 0,
+  PrimalFeasible,
+  DualFeasible,
+  PrimalFeasibleJumpDetected,
+  DualFeasibleJumpDetected,
+  MaxIterationsExceeded,
+  MaxRuntimeExceeded,
+  MaxComplementarityExceeded,
+  PrimalStepTooSmall,
+  DualStepTooSmall
+};
+inline const char *terminate_string(int r)
+{
+  static const char *names[] = {"found primal-dual optimal solution",
+                                "found primal feasible solution",
+                                "found dual feasible solution",
+                                "primal feasible jump detected",
+                                "dual feasible jump detected",
+                                "maxIterations exceeded",
+                                "maxRuntime exceeded",
+                                "maxComplementarity exceeded",
+                                "primal step too small",
+                                "dual step too small"};
+  return (r < 0 || r > 9) ? "" : names[r];
+}
+
+// Static block -> GPU assignment: longest-processing-time greedy on an analytic
+// cost (the quantities the reference measures into block_timings: cholesky_ +
+// solve_ + syrk share, bigint_syrk/Readme.md:325-342; analogue of
+// compute_block_grid_mapping.hxx:58-183).  Deterministic, identical on every rank.
+inline std::vector<int> plan_block_owners(const std::vector<int> &dims, const std::vector<int> &num_points, int N, int world)
+{
+  const int J = (int)dims.size();
+  std::vector<double> cost(J);
+  for(int j = 0; j < J; ++j)
+    {
+      const double m = dims[j], K = num_points[j], P = K * m * (m + 1) / 2;
+      const double n0 = m * ((num_points[j] + 1) / 2), n1 = m * K - n0;
+      cost[j] = P * P * P / 3 + P * P * N + P * (double)N * N / 2 + 8 * P * P + 5 * (n0 * n0 * n0 + n1 * n1 * n1);
+    }
+  std::vector<int> order(J), owner(J, 0);
+  for(int j = 0; j < J; ++j)
+    order[j] = j;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  std::vector<double> load(world, 0.0);
+  for(int j : order)
+    {
+      int best = 0;
+      for(int r = 1; r < world; ++r)
+        if(load[r] < load[best])
+          best = r;
+      owner[j] = best;
+      load[best] += cost[j];
+    }
+  return owner;
+}
+
+class SolverBase
+{
+public:
+  virtual ~SolverBase() {}
+  virtual void set_param(const std::string &name, const char *value) = 0;
+  virtual void set_flags(long max_iterations, bool fpf, bool fdf, bool dpfj, bool ddfj) = 0;
+  virtual void set_block(int j, const char *be, const char *bo, const char *B, const char *c) = 0;
+  virtual void set_objective(const char *b, const char *constant) = 0;
+  virtual void init_state() = 0;
+  virtual bool iterate() = 0;
+  virtual int terminate_reason() const = 0;
+  virtual std::string get_scalar(const std::string &name) = 0;
+  virtual std::string get_array(const std::string &which, int j, int parity) = 0;
+  virtual void set_array(const std::string &which, int j, int parity, const char *txt) = 0;
+  virtual int block_owner(int j) const = 0;
+  virtual void set_collectives(const Collectives &c) = 0;
+  virtual std::string timers_json() const = 0;
+  virtual int limbs() const = 0;
+  // operator-level entry points for parity tests
+  virtual std::string op_scalar(const std::string &op, const char *a, const char *b) = 0;
+  virtual std::string op_int_syrk(int rows, int cols, const char *ints_colmajor) = 0;
+};
+
+template <class... KArgs, class... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args &&...args)
+{
+  if(grid.x == 0 || grid.y == 0 || grid.z == 0)
+    return;
+  hipLaunchKernelGGL(kernel, grid, block, 0, stream, std::forward<Args>(args)...);
+  HIP_CHECK(hipGetLastError());
+}
+
+inline void split_numbers(const char *txt, std::vector<std::pair<const char *, const char *>> &out)
+{
+  out.clear();
+  const char *p = txt;
+  while(*p)
+    {
+      while(*p == ' ' || *p == '\n' || *p == '\t' || *p == ',' || *p == '\r')
+        ++p;
+      if(!*p)
+        break;
+      const char *q = p;
+      while(*q && *q != ' ' && *q != '\n' && *q != '\t' && *q != ',' && *q != '\r')
+        ++q;
+      out.emplace_back(p, q);
+      p = q;
+    }
+}
+
+template <int NL> class Solver : public SolverBase
+{
+  using M = Mw<NL>;
+  static constexpr int FX = NL - 2; // 32*FX = GMP's rounded precision 64*(l-1) (compute_Q.cxx:107)
+  static constexpr int ACCW = 2 * FX + 2;
+  static constexpr int SYRK_RB = 8;
+
+  // ---- problem shape -------------------------------------------------------
+  int precision_, J_, N_, rank_, world_;
+  std::vector<int> dims_, npts_, owner_;
+  std::vector<int> local_; // global indices of the blocks this rank owns
+  std::vector<BlockDesc> blk_;
+  int Jl_ = 0;
+  size_t Ptot_ = 0;        // local sum of P_j
+  size_t psd_elems_ = 0, psd_rows_local_ = 0;
+  long total_psd_rows_ = 0; // global (step.cxx:143)
+  hipStream_t stream_ = nullptr;
+
+  // ---- descriptors -----------------------------------------------------------
+  DevBuf<BlockDesc> d_blk_;
+  DevBuf<MatDesc> d_psd_, d_bases_, d_E_, d_pair_, d_schur_, d_bt_, d_vecP_, d_vecn_, d_Q_, d_vecQ_;
+  std::vector<MatDesc> h_psd_, h_bases_, h_E_, h_pair_, h_schur_, h_bt_, h_vecP_, h_vecn_;
+  // blocked Cholesky(Q): per panel descriptors
+  DevBuf<MatDesc> d_qdiag_, d_qdiagv_, d_qpanel_, d_qtrail_;
+  int q_nb_ = 0, q_panels_ = 0;
+  int max_n_ = 0, max_q_ = 0, max_P_ = 0;
+
+  // ---- device arrays ---------------------------------------------------------
+  DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
+  DevArray bases_, E_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
+  DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_;
+  DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
+  DevBuf<uint32_t> fx_, acc_;
+  DevBuf<unsigned long long> acc64_;
+  DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
+  size_t fx_stride_ = 0, acc_stride_ = 0;
+
+  // ---- parameters (Solver_Parameters.hxx:13-30) --------------------------------
+  M duality_gap_threshold_, primal_error_threshold_, dual_error_threshold_, initial_matrix_scale_primal_,
+    initial_matrix_scale_dual_, feasible_centering_parameter_, infeasible_centering_parameter_, step_length_reduction_,
+    max_complementarity_, min_primal_step_, min_dual_step_;
+  long max_iterations_ = 500;
+  bool find_primal_feasible_ = false, find_dual_feasible_ = false, detect_primal_feasible_jump_ = false,
+       detect_dual_feasible_jump_ = false;
+
+  // ---- scalars (SDP_Solver.hxx:44-74, print_iteration.cxx:91-104) ---------------
+  M objective_const_, primal_objective_, dual_objective_, duality_gap_, primal_error_P_, primal_error_p_, dual_error_,
+    R_error_, mu_, beta_corrector_, primal_step_length_, dual_step_length_, Q_cond_number_, max_block_cond_number_;
+  std::string max_block_cond_number_name_;
+  long iteration_ = 0;
+  int terminate_reason_ = NotTerminated;
+  Collectives coll_;
+  std::map<std::string, double> timers_ms_;
+  std::vector<std::pair<std::string, double>> timer_order_;
+
+  enum ScalSlot
+  {
+    S_MU = 0,
+    S_BETAMU,
+    S_ALPHA_P,
+    S_ALPHA_D,
+    S_COUNT
+  };
+
+public:
+  Solver(int precision_bits, const std::vector<int> &dims, const std::vector<int> &num_points, int N, int rank, int world)
+      : precision_(precision_bits), J_((int)dims.size()), N_(N), rank_(rank), world_(world), dims_(dims), npts_(num_points)
+  {
+    if(N <= 0 || J_ <= 0)
+      throw SolverError(4, "sdpb_hip_create: need at least one block and N >= 1");
+    owner_ = plan_block_owners(dims, num_points, N, world);
+    HIP_CHECK(hipStreamCreate(&stream_));
+    build_layout();
+    set_default_params();
+  }
+  ~Solver() override
+  {
+    if(stream_)
+      (void)hipStreamDestroy(stream_);
+  }
+  int limbs() const override { return NL; }
+  int block_owner(int j) const override { return owner_.at(j); }
+  void set_collectives(const Collectives &c) override { coll_ = c; }
+  int terminate_reason() const override { return terminate_reason_; }
+
+private:
+  // ==========================================================================
+  // layout
+  // ==========================================================================
+  void build_layout()
+  {
+    size_t off_psd = 0, off_bases = 0, off_E = 0, off_pair = 0, off_schur = 0, off_bt = 0, off_vecn = 0;
+    for(int j = 0; j < J_; ++j)
+      {
+        const int m = dims_[j], K = npts_[j];
+        const int n0 = m * ((K + 1) / 2), n1 = m * K - n0;
+        total_psd_rows_ += n0 + n1;
+        if(owner_[j] != rank_)
+          continue;
+        local_.push_back(j);
+        BlockDesc bd;
+        bd.m = m;
+        bd.K = K;
+        bd.P = K * m * (m + 1) / 2;
+        const int d = K - 1;
+        bd.rows[0] = d / 2 + 1;
+        bd.rows[1] = (d + 1) / 2;
+        bd.n[0] = n0;
+        bd.n[1] = n1;
+        bd.voff = Ptot_;
+        bd.global_index = j;
+        blk_.push_back(bd);
+        for(int b = 0; b < 2; ++b)
+          {
+            const int n = bd.n[b], q = m * K;
+            h_psd_.push_back(MatDesc{off_psd, n, n, n, K});
+            h_vecn_.push_back(MatDesc{off_vecn, n, 1, n, K});
+            h_bases_.push_back(MatDesc{off_bases, bd.rows[b], K, bd.rows[b], K});
+            h_E_.push_back(MatDesc{off_E, n, q, n, K});
+            h_pair_.push_back(MatDesc{off_pair, q, q, q, K});
+            off_psd += (size_t)n * n;
+            off_vecn += n;
+            off_bases += (size_t)bd.rows[b] * K;
+            off_E += (size_t)n * q;
+            off_pair += (size_t)q * q;
+            max_n_ = std::max(max_n_, n);
+            max_q_ = std::max(max_q_, q);
+          }
+        h_schur_.push_back(MatDesc{off_schur, bd.P, bd.P, bd.P, K});
+        h_bt_.push_back(MatDesc{off_bt, N_, bd.P, N_, K});
+        h_vecP_.push_back(MatDesc{(unsigned long long)Ptot_, bd.P, 1, bd.P, K});
+        off_schur += (size_t)bd.P * bd.P;
+        off_bt += (size_t)N_ * bd.P;
+        Ptot_ += bd.P;
+        max_P_ = std::max(max_P_, bd.P);
+      }
+    Jl_ = (int)local_.size();
+    psd_elems_ = off_psd;
+    psd_rows_local_ = off_vecn;
+
+    d_blk_.upload(blk_);
+    d_psd_.upload(h_psd_);
+    d_vecn_.upload(h_vecn_);
+    d_bases_.upload(h_bases_);
+    d_E_.upload(h_E_);
+    d_pair_.upload(h_pair_);
+    d_schur_.upload(h_schur_);
+    d_bt_.upload(h_bt_);
+    d_vecP_.upload(h_vecP_);
+    d_Q_.upload(std::vector<MatDesc>{MatDesc{0, N_, N_, N_, 0}});
+    d_vecQ_.upload(std::vector<MatDesc>{MatDesc{0, N_, 1, N_, 0}});
+
+    // blocked Cholesky(Q) panels
+    q_nb_ = N_ <= 96 ? N_ : 32;
+    q_panels_ = (N_ + q_nb_ - 1) / q_nb_;
+    std::vector<MatDesc> qd, qdv, qp, qt;
+    for(int p = 0; p < q_panels_; ++p)
+      {
+        const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
+        qd.push_back(MatDesc{(unsigned long long)k0 + (unsigned long long)k0 * N_, nb, nb, N_, 0});
+        qdv.push_back(MatDesc{(unsigned long long)k0, nb, 1, nb, 0});
+        qp.push_back(MatDesc{(unsigned long long)(k0 + nb) + (unsigned long long)k0 * N_, rest, nb, N_, 0});
+        qt.push_back(MatDesc{(unsigned long long)(k0 + nb) + (unsigned long long)(k0 + nb) * N_, rest, rest, N_, 0});
+      }
+    d_qdiag_.upload(qd);
+    d_qdiagv_.upload(qdv);
+    d_qpanel_.upload(qp);
+    d_qtrail_.upload(qt);
+
+    for(DevArray *a : {&X_, &Y_, &Xc_, &Yc_, &dX_, &dY_, &PR_, &mXY_, &R_, &Z_, &W_})
+      a->alloc(off_psd, NL);
+    bases_.alloc(off_bases, NL);
+    for(DevArray *a : {&E_, &T_, &YQ_})
+      a->alloc(off_E, NL);
+    AX_.alloc(off_pair, NL);
+    AY_.alloc(off_pair, NL);
+    S_.alloc(off_schur, NL);
+    BT_.alloc(off_bt, NL);
+    PT_.alloc(off_bt, NL);
+    for(DevArray *a : {&c_, &x_, &dx_, &dres_, &invdS_})
+      a->alloc(Ptot_, NL);
+    invdX_.alloc(off_vecn, NL);
+    invdY_.alloc(off_vecn, NL);
+    for(DevArray *a : {&b_, &y_, &dy_, &rp_, &norms_, &invnorms_, &invdQ_})
+      a->alloc(N_, NL);
+    Q_.alloc((size_t)N_ * N_, NL);
+    part_.alloc((size_t)std::max(Jl_, 1) * N_, NL);
+    red_.alloc(1024, NL);
+    red2_.alloc(4, NL);
+    lam_.alloc(std::max(2 * Jl_, 1), NL);
+    ratio_.alloc((size_t)5 * std::max(Jl_, 1) + 1, NL);
+    scal_.alloc(S_COUNT, NL);
+    fx_stride_ = off_bt ? off_bt : 1;
+    fx_.alloc(fx_stride_ * (FX + 1));
+    acc_stride_ = (size_t)N_ * N_;
+    acc_.alloc(acc_stride_ * ACCW);
+    if(world_ > 1)
+      acc64_.alloc(acc_stride_ * ACCW);
+    flags_.alloc((size_t)2 * std::max(Jl_, 1) + 4);
+  }
+
+  void set_default_params()
+  {
+    // Solver_Parameters.cxx:10-157
+    set_param("dualityGapThreshold", "1e-30");
+    set_param("primalErrorThreshold", "1e-30");
+    set_param("dualErrorThreshold", "1e-30");
+    set_param("initialMatrixScalePrimal", "1e20");
+    set_param("initialMatrixScaleDual", "1e20");
+    set_param("feasibleCenteringParameter", "0.1");
+    set_param("infeasibleCenteringParameter", "0.3");
+    set_param("stepLengthReduction", "0.7");
+    set_param("maxComplementarity", "1e100");
+    set_param("minPrimalStep", "0");
+    set_param("minDualStep", "0");
+  }
+
+  // ---- batches -----------------------------------------------------------------
+  Batch psd(const DevArray &a) const { return Batch{a.ptr(), d_psd_.p, 2 * Jl_}; }
+  Batch vecn(const DevArray &a) const { return Batch{a.ptr(), d_vecn_.p, 2 * Jl_}; }
+  Batch basesB() const { return Batch{bases_.ptr(), d_bases_.p, 2 * Jl_}; }
+  Batch eB(const DevArray &a) const { return Batch{a.ptr(), d_E_.p, 2 * Jl_}; }
+  Batch pairB(const DevArray &a) const { return Batch{a.ptr(), d_pair_.p, 2 * Jl_}; }
+  Batch schurB() const { return Batch{S_.ptr(), d_schur_.p, Jl_}; }
+  Batch btB(const DevArray &a) const { return Batch{a.ptr(), d_bt_.p, Jl_}; }
+  Batch vecPB(const DevArray &a) const { return Batch{a.ptr(), d_vecP_.p, Jl_}; }
+  Batch QB() const { return Batch{Q_.ptr(), d_Q_.p, 1}; }
+  Batch vecQB(const DevArray &a) const { return Batch{a.ptr(), d_vecQ_.p, 1}; }
+
+  // ---- timers (names follow the reference's Scoped_Timer hierarchy, §5) -----------
+  struct Timer
+  {
+    Solver *s;
+    std::string name;
+    std::chrono::steady_clock::time_point t0;
+    Timer(Solver *s_, const std::string &n) : s(s_), name(n)
+    {
+      t0 = std::chrono::steady_clock::now();
+    }
+    ~Timer()
+    {
+      (void)hipStreamSynchronize(s->stream_);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if(!s->timers_ms_.count(name))
+        s->timer_order_.emplace_back(name, 0.0);
+      s->timers_ms_[name] += ms;
+    }
+  };
+
+public:
+  std::string timers_json() const override
+  {
+    std::ostringstream ss;
+    ss << "{";
+    bool first = true;
+    for(auto &kv : timer_order_)
+      {
+        ss << (first ? "" : ", ") << "\"" << kv.first << "\": " << timers_ms_.at(kv.first);
+        first = false;
+      }
+    ss << "}";
+    return ss.str();
+  }
+
+  // ==========================================================================
+  // inputs
+  // ==========================================================================
+  void set_param(const std::string &n, const char *value) override
+  {
+    const M v = mw::from_decimal<NL>(value);
+    if(n == "dualityGapThreshold") duality_gap_threshold_ = v;
+    else if(n == "primalErrorThreshold") primal_error_threshold_ = v;
+    else if(n == "dualErrorThreshold") dual_error_threshold_ = v;
+    else if(n == "initialMatrixScalePrimal") initial_matrix_scale_primal_ = v;
+    else if(n == "initialMatrixScaleDual") initial_matrix_scale_dual_ = v;
+    else if(n == "feasibleCenteringParameter") feasible_centering_parameter_ = v;
+    else if(n == "infeasibleCenteringParameter") infeasible_centering_parameter_ = v;
+    else if(n == "stepLengthReduction") step_length_reduction_ = v;
+    else if(n == "maxComplementarity") max_complementarity_ = v;
+    else if(n == "minPrimalStep") min_primal_step_ = v;
+    else if(n == "minDualStep") min_dual_step_ = v;
+    else throw SolverError(4, "unknown parameter " + n);
+  }
+  void set_flags(long max_iterations, bool fpf, bool fdf, bool dpfj, bool ddfj) override
+  {
+    max_iterations_ = max_iterations;
+    find_primal_feasible_ = fpf;
+    find_dual_feasible_ = fdf;
+    detect_primal_feasible_jump_ = dpfj;
+    detect_dual_feasible_jump_ = ddfj;
+  }
+
+  std::vector<M> parse_list(const char *txt, size_t expect, const char *what)
+  {
+    std::vector<std::pair<const char *, const char *>> tok;
+    split_numbers(txt, tok);
+    if(tok.size() != expect)
+      throw SolverError(4, std::string("wrong element count for ") + what + ": got " + std::to_string(tok.size())
+                             + ", expected " + std::to_string(expect));
+    std::vector<M> v(expect);
+    for(size_t i = 0; i < expect; ++i)
+      v[i] = mw::from_decimal<NL>(tok[i].first, tok[i].second);
+    return v;
+  }
+  int local_index(int j) const
+  {
+    for(int l = 0; l < Jl_; ++l)
+      if(local_[l] == j)
+        return l;
+    return -1;
+  }
+
+  // Text blobs in the JSON's row-major order (Json_Block_Data_Parser.hxx:26-36).
+  // Blocks owned by other ranks are ignored (every rank may be fed the whole SDP).
+  void set_block(int j, const char *be, const char *bo, const char *B, const char *c) override
+  {
+    if(j < 0 || j >= J_)
+      throw SolverError(4, "set_block: block index out of range");
+    const int l = local_index(j);
+    if(l < 0)
+      return;
+    const BlockDesc &bd = blk_[l];
+    const char *src[2] = {be, bo};
+    for(int b = 0; b < 2; ++b)
+      {
+        const int rs = bd.rows[b];
+        std::vector<M> v = parse_list(src[b], (size_t)rs * bd.K, "bilinear_bases"), cm((size_t)rs * bd.K);
+        for(int r = 0; r < rs; ++r)
+          for(int k = 0; k < bd.K; ++k)
+            cm[(size_t)k * rs + r] = v[(size_t)r * bd.K + k];
+        upload<NL>(bases_, h_bases_[2 * l + b].off, cm);
+      }
+    {
+      // B[p][n] row-major is exactly B^T (N x P) column-major: element (n,p) at n + p*N
+      std::vector<M> v = parse_list(B, (size_t)bd.P * N_, "B");
+      upload<NL>(BT_, h_bt_[l].off, v);
+    }
+    upload<NL>(c_, bd.voff, parse_list(c, bd.P, "c"));
+    // bases_blocks (set_bases_blocks.cxx:3-22) for this block's two parities
+    Batch bb = basesB(), ee = eB(E_);
+    bb.d += 2 * l;
+    ee.d += 2 * l;
+    bb.count = ee.count = 2;
+    const size_t mx = std::max((size_t)bd.n[0] * bd.m * bd.K, (size_t)bd.n[1] * bd.m * bd.K);
+    launch(k_build_bases_block<NL>, dim3(cdiv(mx, WG), 2), dim3(WG), stream_, bb, ee, d_blk_.p + l); // the kernel indexes blk[q>>1], q in {0,1}: relative to this block
+    HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  void set_objective(const char *b, const char *constant) override
+  {
+    upload<NL>(b_, 0, parse_list(b, N_, "b"));
+    objective_const_ = mw::from_decimal<NL>(constant);
+  }
+
+  // SDP_Solver.cxx:23-38
+  void init_state() override
+  {
+    for(DevArray *a : {&X_, &Y_, &x_, &y_, &dx_, &dy_, &dX_, &dY_})
+      HIP_CHECK(hipMemsetAsync(a->base, 0, a->bytes(), stream_));
+    upload_scalar(S_ALPHA_P, initial_matrix_scale_primal_);
+    upload_scalar(S_ALPHA_D, initial_matrix_scale_dual_);
+    add_diagonal(X_, S_ALPHA_P);
+    add_diagonal(Y_, S_ALPHA_D);
+    iteration_ = 0;
+    terminate_reason_ = NotTerminated;
+    primal_step_length_ = mw::zero<NL>();
+    dual_step_length_ = mw::zero<NL>();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+
+private:
+  // ==========================================================================
+  // small device helpers
+  // ==========================================================================
+  void upload_scalar(int slot, const M &v) { upload<NL>(scal_, slot, std::vector<M>{v}); }
+
+  template <class F> void foreach(size_t count, F f)
+  {
+    if(!count)
+      return;
+    launch(k_foreach<F>, dim3(std::min<unsigned>(cdiv(count, WG), 4096)), dim3(WG), stream_, count, f);
+  }
+  // two-stage reduction; returns the value on the host.  Empty range -> 0.
+  template <int OP, class F> M reduce(size_t count, F f)
+  {
+    if(!count)
+      return mw::zero<NL>();
+    const unsigned g = std::min<unsigned>(cdiv(count, WG), 512);
+    launch(k_reduce<NL, OP, F>, dim3(g), dim3(WG), stream_, count, f, red_.ptr());
+    mw::CPtr rp = red_.cptr();
+    auto ld = [rp] __device__(size_t i) { return mw::load<NL>(rp, i); };
+    launch(k_reduce<NL, OP, decltype(ld)>, dim3(1), dim3(WG), stream_, (size_t)g, ld, red2_.ptr());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return download<NL>(red2_, 0, 1)[0];
+  }
+  // cross-rank combination of a host scalar (all ranks end with identical bits)
+  M allreduce_scalar(const M &v, int op)
+  {
+    if(world_ == 1)
+      return v;
+    std::vector<M> all = allgather(std::vector<M>{v});
+    M r = all[0];
+    for(int k = 1; k < world_; ++k)
+      r = op == RED_SUM ? mw::add(r, all[k]) : (op == RED_MAX ? mw::max(r, all[k]) : mw::min(r, all[k]));
+    return r;
+  }
+  // gather a short host vector from every rank (rank order)
+  std::vector<M> allgather(const std::vector<M> &v)
+  {
+    if(world_ == 1)
+      return v;
+    if(!coll_.allgather_bytes)
+      throw SolverError(4, "world_size > 1 but no collectives were registered (sdpb_hip_set_collectives)");
+    const size_t words = (size_t)(NL + 2) * v.size();
+    DevBuf<uint32_t> send, recv;
+    send.alloc(words);
+    recv.alloc(words * world_);
+    std::vector<uint32_t> h(words);
+    for(size_t i = 0; i < v.size(); ++i)
+      {
+        h[i * (NL + 2)] = (uint32_t)v[i].e;
+        h[i * (NL + 2) + 1] = v[i].neg;
+        for(int k = 0; k < NL; ++k)
+          h[i * (NL + 2) + 2 + k] = v[i].m[k];
+      }
+    HIP_CHECK(hipMemcpy(send.p, h.data(), words * 4, hipMemcpyHostToDevice));
+    if(coll_.allgather_bytes(coll_.user, send.p, recv.p, words * 4) != 0)
+      throw HipError(3, "allgather callback failed");
+    std::vector<uint32_t> g = recv.download();
+    std::vector<M> out(v.size() * world_);
+    for(size_t i = 0; i < out.size(); ++i)
+      {
+        out[i].e = (int32_t)g[i * (NL + 2)];
+        out[i].neg = g[i * (NL + 2) + 1];
+        for(int k = 0; k < NL; ++k)
+          out[i].m[k] = g[i * (NL + 2) + 2 + k];
+      }
+    return out;
+  }
+  // Sum an N-vector held in a device array across ranks (deterministic: gathered and
+  // added in rank order on every rank).
+  void allreduce_vec_sum(DevArray &a, size_t count)
+  {
+    if(world_ == 1)
+      return;
+    std::vector<M> mine = download<NL>(a, 0, count);
+    std::vector<M> all = allgather(mine);
+    for(size_t i = 0; i < count; ++i)
+      {
+        M s = all[i];
+        for(int k = 1; k < world_; ++k)
+          s = mw::add(s, all[(size_t)k * count + i]);
+        mine[i] = s;
+      }
+    upload<NL>(a, 0, mine);
+  }
+
+  void copy(const DevArray &src, DevArray &dst)
+  {
+    HIP_CHECK(hipMemcpyAsync(dst.base, src.base, src.bytes(), hipMemcpyDeviceToDevice, stream_));
+  }
+  // Block_Diagonal_Matrix::add_diagonal (Block_Diagonal_Matrix.hxx:63-69); c = scal_[slot]
+  void add_diagonal(DevArray &A, int slot)
+  {
+    const MatDesc *d = d_vecn_.p;
+    const MatDesc *dp = d_psd_.p;
+    mw::Ptr a = A.ptr();
+    mw::CPtr sc = scal_.cptr();
+    const int nq = 2 * Jl_;
+    // one lane per diagonal element: walk the (small) descriptor table to find the matrix
+    foreach(psd_rows_local_, [=] __device__(size_t i) {
+      int q = 0;
+      while(q + 1 < nq && d[q + 1].off <= i)
+        ++q;
+      const int r = (int)(i - d[q].off);
+      const size_t e = (size_t)dp[q].off + (size_t)r * (dp[q].ld + 1);
+      mw::store<NL>(a, e, mw::add(mw::load<NL>(a, e), mw::load<NL>(sc, slot)));
+    });
+  }
+  // A = (A + A^T)/2, optionally negated (Block_Diagonal_Matrix::symmetrize :95-109)
+  void symmetrize(DevArray &A, bool negate)
+  {
+    launch(k_symmetrize<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(A), (int)negate);
+  }
+  void check_chol_flags(int count, const char *what, bool schur)
+  {
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    std::vector<int> f = flags_.download();
+    for(int q = 0; q < count; ++q)
+      if(f[q])
+        {
+          std::ostringstream ss;
+          if(schur) // compute_Q.cxx:36-38
+            ss << "Error when computing Cholesky decomposition of block_" << local_[q] << ": A was not numerically HPD";
+          else // cholesky_decomposition.cxx:22-25
+            ss << "Error when computing Cholesky decomposition of Block_Diagonal_Matrix " << what
+               << ", block index = " << local_[q / 2] << ", parity = " << q % 2 << ": A was not numerically HPD";
+          throw SolverError(1, ss.str());
+        }
+  }
+  void clear_flags() { HIP_CHECK(hipMemsetAsync(flags_.p, 0, flags_.n * sizeof(int), stream_)); }
+
+  // cholesky_decomposition.cxx:5-28
+  void cholesky_psd(const DevArray &A, DevArray &L, DevArray &invd, const char *name)
+  {
+    copy(A, L);
+    clear_flags();
+    launch(k_chol_lower<NL>, dim3(2 * Jl_), dim3(WG), stream_, psd(L), vecn(invd), flags_.p);
+    check_chol_flags(2 * Jl_, name, false);
+  }
+  void gemm_psd(bool ta, const DevArray &A, const DevArray &B, DevArray &C, bool alpha_neg, bool beta_one)
+  {
+    const unsigned tiles = cdiv(max_n_, 16) * cdiv(max_n_, 16);
+    if(ta)
+      launch(k_gemm<NL, true>, dim3(tiles, 2 * Jl_), dim3(WG), stream_, psd(A), psd(B), psd(C), (int)alpha_neg, (int)beta_one, 0);
+    else
+      launch(k_gemm<NL, false>, dim3(tiles, 2 * Jl_), dim3(WG), stream_, psd(A), psd(B), psd(C), (int)alpha_neg, (int)beta_one, 0);
+  }
+  // cholesky_solve.cxx:4-13 : A := Xc^{-T} Xc^{-1} A
+  void cholesky_solve_X(DevArray &A)
+  {
+    launch(k_trsm_lln<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(A));
+    launch(k_trsm_llt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(A));
+  }
+
+  // ==========================================================================
+  // the iteration
+  // ==========================================================================
+  // compute_objectives.cxx:6-29, dot.cxx:4-22
+  void compute_objectives()
+  {
+    Timer t(this, "objectives");
+    mw::CPtr c = c_.cptr(), x = x_.cptr(), b = b_.cptr(), y = y_.cptr();
+    M cx = reduce<RED_SUM>(Ptot_, [=] __device__(size_t i) { return mw::mul(mw::load<NL>(c, i), mw::load<NL>(x, i)); });
+    cx = allreduce_scalar(cx, RED_SUM);
+    const M by = reduce<RED_SUM>((size_t)N_, [=] __device__(size_t i) { return mw::mul(mw::load<NL>(b, i), mw::load<NL>(y, i)); });
+    primal_objective_ = mw::add(objective_const_, cx);
+    dual_objective_ = mw::add(objective_const_, by);
+    const M denom = mw::max(mw::add(mw::abs(primal_objective_), mw::abs(dual_objective_)), mw::from_u32<NL>(1));
+    duality_gap_ = mw::div(mw::abs(mw::sub(primal_objective_, dual_objective_)), denom);
+  }
+
+  // compute_bilinear_pairings.cxx:17-31
+  void compute_bilinear_pairings()
+  {
+    Timer t(this, "bilinear_pairings");
+    const unsigned tiles_q = cdiv(max_q_, 16) * cdiv(max_q_, 16);
+    // A_X_inv = (Xc^{-1} E)^T (Xc^{-1} E)      compute_A_X_inv.cxx:18-29
+    copy(E_, T_);
+    launch(k_trsm_lln<NL>, dim3(cdiv(max_q_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), eB(T_));
+    launch(k_gemm<NL, true>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, eB(T_), eB(T_), pairB(AX_), 0, 0, 1);
+    // A_Y = E^T (Y E)                           compute_A_Y.cxx:30-45
+    launch(k_gemm<NL, false>, dim3(cdiv(max_n_, 16) * cdiv(max_q_, 16), 2 * Jl_), dim3(WG), stream_, psd(Y_), eB(E_), eB(YQ_), 0, 0, 0);
+    launch(k_gemm<NL, true>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, eB(E_), eB(YQ_), pairB(AY_), 0, 0, 1);
+  }
+
+  M max_abs(const DevArray &a, size_t count)
+  {
+    mw::CPtr p = a.cptr();
+    return reduce<RED_MAX>(count, [=] __device__(size_t i) { return mw::abs(mw::load<NL>(p, i)); });
+  }
+
+  // compute_dual_residues_and_error.cxx:7-66
+  void compute_dual_residues_and_error()
+  {
+    Timer t(this, "computeDualResidues");
+    launch(k_dual_residues<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, pairB(AY_), btB(BT_), c_.cptr(), y_.cptr(),
+           dres_.ptr(), d_blk_.p, N_);
+    dual_error_ = allreduce_scalar(max_abs(dres_, Ptot_), RED_MAX);
+  }
+  // constraint_matrix_weighted_sum.cxx:14-66 (+ the add/subtract that follows it)
+  void constraint_matrix_weighted_sum(const DevArray &a, DevArray &out, const DevArray &addend, int sign)
+  {
+    launch(k_constraint_weighted_sum<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, basesB(), a.cptr(),
+           psd(out), psd(addend), sign, d_blk_.p);
+  }
+  // compute_primal_residues_and_error_P_Ax_X.cxx:5-14
+  void compute_primal_residues_P()
+  {
+    Timer t(this, "computePrimalResidues");
+    constraint_matrix_weighted_sum(x_, PR_, X_, -1);
+    primal_error_P_ = allreduce_scalar(max_abs(PR_, psd_elems_), RED_MAX);
+  }
+  // out[n] = base[n] + sign * sum_blocks (M_j^T v_j)[n], summed over all ranks
+  template <bool SQUARE> void gemv_t_all(const DevArray &MT, const DevArray &v, const DevArray *base, int sign, DevArray &out)
+  {
+    launch(k_gemv_t_partial<NL, SQUARE>, dim3(cdiv(N_, WG), Jl_), dim3(WG), stream_, btB(MT), v.cptr(), part_.ptr(), d_blk_.p, N_);
+    if(world_ == 1)
+      {
+        launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part_.cptr(), Jl_, N_, base ? base->cptr() : out.cptr(),
+               base ? 1 : 0, sign, out.ptr());
+        return;
+      }
+    // local sum, cross-rank sum, then base + sign*sum
+    launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part_.cptr(), Jl_, N_, out.cptr(), 0, 1, out.ptr());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    allreduce_vec_sum(out, N_);
+    mw::Ptr o = out.ptr();
+    mw::CPtr bs = base ? base->cptr() : out.cptr();
+    const int has = base ? 1 : 0, sg = sign;
+    foreach((size_t)N_, [=] __device__(size_t i) {
+      M s = mw::load<NL>(o, i);
+      if(sg < 0)
+        s = mw::neg(s);
+      if(has)
+        s = mw::add(mw::load<NL>(bs, i), s);
+      mw::store<NL>(o, i, s);
+    });
+  }
+  // compute_primal_residues_and_error_p_b_Bx.cxx:9-86
+  void compute_primal_residue_p()
+  {
+    Timer t(this, "computePrimalResidue_p");
+    gemv_t_all<false>(BT_, x_, &b_, -1, rp_);
+    primal_error_p_ = max_abs(rp_, N_);
+  }
+
+  // compute_feasible_and_termination.cxx:4-71 (no wall-clock reason here: maxRuntime
+  // belongs to the caller's loop)
+  bool compute_feasible_and_termination(bool &feasible)
+  {
+    const M perr = mw::max(primal_error_P_, primal_error_p_);
+    const bool dualf = mw::lt(dual_error_, dual_error_threshold_), primf = mw::lt(perr, primal_error_threshold_);
+    feasible = primf && dualf;
+    const bool optimal = mw::lt(duality_gap_, duality_gap_threshold_);
+    const M one = mw::from_u32<NL>(1);
+    if(feasible && optimal)
+      terminate_reason_ = PrimalDualOptimal;
+    else if(dualf && find_dual_feasible_)
+      terminate_reason_ = DualFeasible;
+    else if(primf && find_primal_feasible_)
+      terminate_reason_ = PrimalFeasible;
+    else if(mw::cmp(dual_step_length_, one) == 0 && detect_dual_feasible_jump_)
+      terminate_reason_ = DualFeasibleJumpDetected;
+    else if(mw::cmp(primal_step_length_, one) == 0 && detect_primal_feasible_jump_)
+      terminate_reason_ = PrimalFeasibleJumpDetected;
+    else if(iteration_ > max_iterations_)
+      terminate_reason_ = MaxIterationsExceeded;
+    else if(iteration_ > 1 && mw::lt(primal_step_length_, min_primal_step_))
+      terminate_reason_ = PrimalStepTooSmall;
+    else if(iteration_ > 1 && mw::lt(dual_step_length_, min_dual_step_))
+      terminate_reason_ = DualStepTooSmall;
+    else
+      return false;
+    return true;
+  }
+
+  // initialize_schur_complement_solver.cxx:62-104
+  void initialize_schur_complement_solver()
+  {
+    {
+      Timer t(this, "initializeSchurComplementSolver.schur_complement");
+      launch(k_schur_complement<NL>, dim3(cdiv((size_t)max_P_ * max_P_, WG), Jl_), dim3(WG), stream_, pairB(AX_), pairB(AY_), schurB(),
+             d_blk_.p);
+    }
+    {
+      // compute_Q.cxx:9-61 : L = chol(S) in place, P^T = B^T L^{-T}
+      Timer t(this, "initializeSchurComplementSolver.Q.cholesky");
+      clear_flags();
+      launch(k_chol_lower<NL>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), flags_.p);
+      check_chol_flags(Jl_, "S", true);
+    }
+    {
+      Timer t(this, "initializeSchurComplementSolver.Q.solve");
+      copy(BT_, PT_);
+      launch(k_trsm_rlt<NL>, dim3(cdiv(N_, WG), Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), btB(PT_));
+    }
+    {
+      // syrk_Q, compute_Q.cxx:94-132
+      Timer t(this, "initializeSchurComplementSolver.Q.syrk");
+      gemv_t_all<true>(PT_, x_, nullptr, 1, norms_); // norms_ = column norms^2 (Matrix_Normalizer.cxx:75-137)
+      {
+        mw::Ptr nr = norms_.ptr(), inv = invnorms_.ptr();
+        foreach((size_t)N_, [=] __device__(size_t i) {
+          const M n2 = mw::load<NL>(nr, i);
+          if(mw::is_zero(n2))
+            {
+              mw::store<NL>(inv, i, n2);
+              return;
+            }
+          const M r = mw::rsqrt(n2);
+          M s = mw::mul(n2, r);
+          s = mw::add(s, mw::mul_2exp(mw::mul(r, mw::sub(n2, mw::mul(s, s))), -1));
+          mw::store<NL>(nr, i, s);
+          mw::store<NL>(inv, i, mw::mul(r, mw::sub(mw::from_u32<NL>(2), mw::mul(s, r))));
+        });
+      }
+      const size_t cnt = Ptot_ * (size_t)N_;
+      if(cnt)
+        launch(k_normalize_fx<NL, FX>, dim3(std::min<unsigned>(cdiv(cnt, WG), 8192)), dim3(WG), stream_, PT_.cptr(), cnt, N_,
+               invnorms_.cptr(), fx_.p, fx_stride_);
+      const unsigned tiles = cdiv(N_, 16);
+      if(cnt)
+        launch(k_syrk_fx<FX, SYRK_RB>, dim3(tiles * (tiles + 1) / 2), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_, (size_t)0,
+               Ptot_, N_, acc_.p, acc_stride_, 0);
+      else
+        HIP_CHECK(hipMemsetAsync(acc_.p, 0, acc_.n * sizeof(uint32_t), stream_));
+      if(world_ > 1)
+        reduce_Q_accumulators();
+      int *qflags = flags_.p + 2 * std::max(Jl_, 1);
+      HIP_CHECK(hipMemsetAsync(qflags, 0, 4 * sizeof(int), stream_));
+      launch(k_restore_Q<NL, FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_,
+             norms_.cptr(), Q_.ptr(), qflags + 1);
+    }
+    {
+      Timer t(this, "initializeSchurComplementSolver.Cholesky_Q");
+      cholesky_Q();
+    }
+  }
+  // exact cross-GPU sum of the fixed-point Q' images
+  void reduce_Q_accumulators()
+  {
+    if(!coll_.allreduce_sum_u64)
+      throw SolverError(4, "world_size > 1 but no collectives were registered (sdpb_hip_set_collectives)");
+    const size_t words = acc_stride_ * ACCW;
+    launch(k_widen_u64<0>, dim3(std::min<unsigned>(cdiv(words, WG), 8192)), dim3(WG), stream_, (const uint32_t *)acc_.p, words, acc64_.p);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if(coll_.allreduce_sum_u64(coll_.user, acc64_.p, words) != 0)
+      throw HipError(3, "allreduce callback failed");
+    launch(k_narrow_carry<0>, dim3(std::min<unsigned>(cdiv(acc_stride_, WG), 8192)), dim3(WG), stream_, (const unsigned long long *)acc64_.p,
+           acc_stride_, ACCW, acc_.p);
+  }
+  // El::Cholesky(UPPER,Q) (initialize_schur_complement_solver.cxx:95-103), stored here
+  // as the lower factor L = U^T; right-looking blocked: diagonal block in one
+  // workgroup, panel rows one lane each, trailing update over the whole chip.
+  void cholesky_Q()
+  {
+    int *qflags = flags_.p + 2 * std::max(Jl_, 1);
+    for(int p = 0; p < q_panels_; ++p)
+      {
+        Batch dg{Q_.ptr(), d_qdiag_.p + p, 1}, dv{invdQ_.ptr(), d_qdiagv_.p + p, 1};
+        launch(k_chol_lower<NL>, dim3(1), dim3(WG), stream_, dg, dv, qflags);
+        const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
+        if(rest <= 0)
+          continue;
+        Batch pn{Q_.ptr(), d_qpanel_.p + p, 1}, tr{Q_.ptr(), d_qtrail_.p + p, 1};
+        launch(k_trsm_rlt<NL>, dim3(cdiv(rest, WG), 1), dim3(WG), stream_, dg, dv, pn);
+        const unsigned tiles = cdiv(rest, 16);
+        launch(k_syrk_down_lower<NL>, dim3(tiles * (tiles + 1) / 2, 1), dim3(WG), stream_, pn, tr);
+      }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    int f[4];
+    HIP_CHECK(hipMemcpy(f, qflags, sizeof f, hipMemcpyDeviceToHost));
+    if(f[1])
+      throw SolverError(1, "Normalized Q should have ones on diagonal. For i = " + std::to_string(f[1] - 1));
+    if(f[0])
+      throw SolverError(1, "Error when computing Cholesky(Q): A was not numerically HPD");
+  }
+
+  // solve_schur_complement_equation.cxx:16-79
+  void solve_schur_complement_equation()
+  {
+    launch(k_vec_solve<NL, false>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
+    gemv_t_all<false>(PT_, dx_, &rp_, -1, dy_); // dy = p - sum_j P_j^T dx_j
+    launch(k_vec_solve<NL, false>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
+    launch(k_vec_solve<NL, true>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
+    launch(k_gemv_n_add<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, btB(PT_), dy_.cptr(), dx_.ptr(), d_blk_.p, N_);
+    launch(k_vec_solve<NL, true>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
+  }
+
+  // compute_search_direction.cxx:44-90
+  void compute_search_direction(const M &beta, bool corrector)
+  {
+    // R = beta mu I - XY (- dX dY)
+    copy(mXY_, R_);
+    if(corrector)
+      gemm_psd(false, dX_, dY_, R_, true, true);
+    upload_scalar(S_BETAMU, mw::mul(beta, mu_));
+    add_diagonal(R_, S_BETAMU);
+    // Z = Symmetrize(X^{-1} (PrimalResidues Y - R))
+    gemm_psd(false, PR_, Y_, Z_, false, false);
+    sub_inplace(Z_, R_);
+    cholesky_solve_X(Z_);
+    symmetrize(Z_, false);
+    // dx = -d - Tr(A_p Z) ; dy = p
+    launch(k_schur_rhs<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, basesB(), psd(Z_), dres_.cptr(), dx_.ptr(), d_blk_.p);
+    solve_schur_complement_equation();
+    // dX = PrimalResidues + sum_p A_p dx[p]
+    constraint_matrix_weighted_sum(dx_, dX_, PR_, +1);
+    // dY = Symmetrize(X^{-1} (R - dX Y))
+    gemm_psd(false, dX_, Y_, dY_, false, false);
+    sub_inplace(dY_, R_);
+    cholesky_solve_X(dY_);
+    symmetrize(dY_, true);
+  }
+  void sub_inplace(DevArray &A, const DevArray &B)
+  {
+    mw::Ptr a = A.ptr();
+    mw::CPtr b = B.cptr();
+    foreach(psd_elems_, [=] __device__(size_t i) { mw::store<NL>(a, i, mw::sub(mw::load<NL>(a, i), mw::load<NL>(b, i))); });
+  }
+
+  // corrector_centering_parameter.cxx:12-31 + frobenius_product_of_sums.cxx:6-31
+  M corrector_centering_parameter(bool feasible)
+  {
+    mw::CPtr X = X_.cptr(), dX = dX_.cptr(), Y = Y_.cptr(), dY = dY_.cptr();
+    M fr = reduce<RED_SUM>(psd_elems_, [=] __device__(size_t i) {
+      return mw::mul(mw::add(mw::load<NL>(X, i), mw::load<NL>(dX, i)), mw::add(mw::load<NL>(Y, i), mw::load<NL>(dY, i)));
+    });
+    fr = allreduce_scalar(fr, RED_SUM);
+    const M r = mw::div(fr, mw::mul(mu_, mw::from_u32<NL>((uint32_t)total_psd_rows_)));
+    const M one = mw::from_u32<NL>(1);
+    const M beta = mw::lt(r, one) ? mw::mul(r, r) : r;
+    if(feasible)
+      return mw::min(mw::max(feasible_centering_parameter_, beta), one);
+    return mw::max(infeasible_centering_parameter_, beta);
+  }
+
+  // step_length.cxx:27-46
+  M step_length(const DevArray &Lc, const DevArray &invd, const DevArray &dM, const char *name)
+  {
+    Timer t(this, name);
+    copy(dM, W_);
+    launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
+    launch(k_trsm_lln<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
+    launch(k_jacobi_min_eig<NL>, dim3(2 * Jl_), dim3(WG), stream_, psd(W_), lam_.ptr(), 100);
+    mw::CPtr lp = lam_.cptr();
+    M lambda = reduce<RED_MIN>((size_t)2 * Jl_, [=] __device__(size_t i) { return mw::load<NL>(lp, i); });
+    if(Jl_ == 0)
+      {
+        lambda = mw::from_u32<NL>(1);
+        lambda.e = 1 << 28;
+      }
+    lambda = allreduce_scalar(lambda, RED_MIN);
+    const M &gamma = step_length_reduction_;
+    if(mw::gt(lambda, mw::neg(gamma)))
+      return mw::from_u32<NL>(1);
+    return mw::div(mw::neg(gamma), lambda);
+  }
+
+  // update_cond_numbers.hxx:16-110
+  void update_cond_numbers()
+  {
+    Timer t(this, "condition_numbers");
+    const int J1 = std::max(Jl_, 1);
+    if(Jl_)
+      {
+        launch(k_diag_ratio<NL>, dim3(cdiv(Jl_, WG)), dim3(WG), stream_, schurB(), ratio_.ptr(), (size_t)0);
+        launch(k_diag_ratio<NL>, dim3(cdiv(2 * Jl_, WG)), dim3(WG), stream_, psd(Xc_), ratio_.ptr(), (size_t)J1);
+        launch(k_diag_ratio<NL>, dim3(cdiv(2 * Jl_, WG)), dim3(WG), stream_, psd(Yc_), ratio_.ptr(), (size_t)3 * J1);
+      }
+    launch(k_diag_ratio<NL>, dim3(1), dim3(WG), stream_, QB(), ratio_.ptr(), (size_t)5 * J1);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    std::vector<M> r = download<NL>(ratio_, 0, (size_t)5 * J1 + 1);
+    Q_cond_number_ = mw::mul(r[5 * J1], r[5 * J1]);
+    // candidates in the reference's scan order (block, then parity: S, X, Y)
+    M best = mw::zero<NL>();
+    int best_global = -1, best_kind = 0, best_parity = 0;
+    for(int l = 0; l < Jl_; ++l)
+      {
+        auto consider = [&](const M &v, int kind, int parity) {
+          const int g = local_[l];
+          const bool better = mw::lt(best, v) || (mw::cmp(best, v) == 0 && best_global >= 0 && g < best_global);
+          if(better && !mw::is_zero(v))
+            {
+              best = v;
+              best_global = g;
+              best_kind = kind;
+              best_parity = parity;
+            }
+        };
+        consider(r[l], 0, 0);
+        for(int b = 0; b < 2; ++b)
+          {
+            consider(r[J1 + 2 * l + b], 1, b);
+            consider(r[3 * J1 + 2 * l + b], 2, b);
+          }
+      }
+    if(world_ > 1)
+      {
+        // every rank proposes (value, global block, kind, parity); winner = max value
+        M tag = mw::from_u32<NL>((uint32_t)std::max(best_global, 0) * 8u + (uint32_t)best_kind * 2u + (uint32_t)best_parity + 1u);
+        std::vector<M> all = allgather(std::vector<M>{best, tag});
+        int w = 0;
+        for(int k = 1; k < world_; ++k)
+          if(mw::lt(all[2 * w], all[2 * k]))
+            w = k;
+        best = all[2 * w];
+        const uint32_t code = (uint32_t)mw::to_double(all[2 * w + 1]) - 1u;
+        best_global = (int)(code / 8u);
+        best_kind = (int)((code % 8u) / 2u);
+        best_parity = (int)(code % 2u);
+      }
+    max_block_cond_number_ = mw::mul(best, best);
+    std::ostringstream ss;
+    if(best_kind == 0)
+      ss << "schur_complement_cholesky.block_" << best_global;
+    else
+      ss << (best_kind == 1 ? "X" : "Y") << "_cholesky.block_" << best_global << "_" << best_parity;
+    max_block_cond_number_name_ = ss.str();
+  }
+
+  // step.cxx:51-229; returns true when mu > maxComplementarity
+  bool step(bool feasible)
+  {
+    initialize_schur_complement_solver();
+    {
+      Timer t(this, "XY");
+      gemm_psd(false, X_, Y_, mXY_, true, false);
+    }
+    {
+      Timer t(this, "mu");
+      // trace: one lane per diagonal element
+      const MatDesc *dv = d_vecn_.p, *dp = d_psd_.p;
+      mw::CPtr a = mXY_.cptr();
+      const int nq = 2 * Jl_;
+      M tr = reduce<RED_SUM>(psd_rows_local_, [=] __device__(size_t i) {
+        int q = 0;
+        while(q + 1 < nq && dv[q + 1].off <= i)
+          ++q;
+        const int r = (int)(i - dv[q].off);
+        return mw::load<NL>(a, (size_t)dp[q].off + (size_t)r * (dp[q].ld + 1));
+      });
+      tr = allreduce_scalar(tr, RED_SUM);
+      mu_ = mw::div(mw::neg(tr), mw::from_u32<NL>((uint32_t)total_psd_rows_));
+    }
+    if(mw::gt(mu_, max_complementarity_))
+      return true;
+    {
+      // compute_R_error.hxx:9-29 : max |(-XY) + mu I|
+      Timer t(this, "R_error");
+      upload_scalar(S_MU, mu_);
+      const MatDesc *dp = d_psd_.p;
+      mw::CPtr a = mXY_.cptr(), sc = scal_.cptr();
+      const int nq = 2 * Jl_;
+      M re = reduce<RED_MAX>(psd_elems_, [=] __device__(size_t i) {
+        int q = 0;
+        while(q + 1 < nq && dp[q + 1].off <= i)
+          ++q;
+        const size_t e = i - (size_t)dp[q].off;
+        const int n = dp[q].rows;
+        M v = mw::load<NL>(a, i);
+        if(e % n == e / n)
+          v = mw::add(v, mw::load<NL>(sc, S_MU));
+        return mw::abs(v);
+      });
+      R_error_ = allreduce_scalar(re, RED_MAX);
+    }
+    {
+      Timer t(this, "computeSearchDirection(betaPredictor)");
+      const M beta_predictor = feasible ? mw::zero<NL>() : infeasible_centering_parameter_; // predictor_centering_parameter.cxx:4-9
+      compute_search_direction(beta_predictor, false);
+    }
+    {
+      Timer t(this, "computeSearchDirection(betaCorrector)");
+      beta_corrector_ = corrector_centering_parameter(feasible);
+      compute_search_direction(beta_corrector_, true);
+    }
+    update_cond_numbers();
+    primal_step_length_ = step_length(Xc_, invdX_, dX_, "stepLength(XCholesky)");
+    dual_step_length_ = step_length(Yc_, invdY_, dY_, "stepLength(YCholesky)");
+    if(feasible)
+      {
+        primal_step_length_ = mw::min(primal_step_length_, dual_step_length_);
+        dual_step_length_ = primal_step_length_;
+      }
+    {
+      // step.cxx:208-224
+      Timer t(this, "update");
+      upload_scalar(S_ALPHA_P, primal_step_length_);
+      upload_scalar(S_ALPHA_D, dual_step_length_);
+      axpy_scalar(S_ALPHA_P, dx_, x_, Ptot_);
+      axpy_scalar(S_ALPHA_P, dX_, X_, psd_elems_);
+      axpy_scalar(S_ALPHA_D, dy_, y_, (size_t)N_);
+      axpy_scalar(S_ALPHA_D, dY_, Y_, psd_elems_);
+    }
+    return false;
+  }
+  void axpy_scalar(int slot, const DevArray &d, DevArray &v, size_t count)
+  {
+    mw::CPtr sc = scal_.cptr(), dd = d.cptr();
+    mw::Ptr vv = v.ptr();
+    foreach(count, [=] __device__(size_t i) {
+      mw::store<NL>(vv, i, mw::add(mw::load<NL>(vv, i), mw::mul(mw::load<NL>(sc, slot), mw::load<NL>(dd, i))));
+    });
+  }
+
+public:
+  // One pass of run.cxx:322-467.  Returns true when the loop terminates.
+  bool iterate() override
+  {
+    iteration_ += 1;
+    compute_objectives();
+    {
+      Timer t(this, "choleskyDecomposition");
+      cholesky_psd(X_, Xc_, invdX_, "X");
+      cholesky_psd(Y_, Yc_, invdY_, "Y");
+    }
+    compute_bilinear_pairings();
+    compute_dual_residues_and_error();
+    compute_primal_residues_P();
+    compute_primal_residue_p();
+    bool feasible = false;
+    if(compute_feasible_and_termination(feasible))
+      return true;
+    Timer t(this, "step");
+    if(step(feasible))
+      {
+        terminate_reason_ = MaxComplementarityExceeded;
+        return true;
+      }
+    return false;
+  }
+
+  // ==========================================================================
+  // outputs
+  // ==========================================================================
+  std::string get_scalar(const std::string &n) override
+  {
+    const M *v = nullptr;
+    M pe;
+    if(n == "mu") v = &mu_;
+    else if(n == "P-obj" || n == "primalObjective") v = &primal_objective_;
+    else if(n == "D-obj" || n == "dualObjective") v = &dual_objective_;
+    else if(n == "gap" || n == "dualityGap") v = &duality_gap_;
+    else if(n == "P-err") v = &primal_error_P_;
+    else if(n == "p-err") v = &primal_error_p_;
+    else if(n == "D-err" || n == "dualError") v = &dual_error_;
+    else if(n == "R-err") v = &R_error_;
+    else if(n == "P-step") v = &primal_step_length_;
+    else if(n == "D-step") v = &dual_step_length_;
+    else if(n == "beta") v = &beta_corrector_;
+    else if(n == "Q_cond_number") v = &Q_cond_number_;
+    else if(n == "max_block_cond_number") v = &max_block_cond_number_;
+    else if(n == "primalError") { pe = mw::max(primal_error_P_, primal_error_p_); v = &pe; }
+    else if(n == "block_name") return max_block_cond_number_name_;
+    else if(n == "iteration") return std::to_string(iteration_);
+    else throw SolverError(4, "unknown scalar " + n);
+    return mw::to_decimal<NL>(*v);
+  }
+
+  struct ArrayRef
+  {
+    DevArray *a;
+    size_t off, count;
+  };
+  ArrayRef locate(const std::string &w, int j, int parity)
+  {
+    if(w == "y") return {&y_, 0, (size_t)N_};
+    if(w == "dy") return {&dy_, 0, (size_t)N_};
+    if(w == "primal_residue_p") return {&rp_, 0, (size_t)N_};
+    if(w == "Q") return {&Q_, 0, (size_t)N_ * N_};
+    if(w == "b") return {&b_, 0, (size_t)N_};
+    const int l = local_index(j);
+    if(l < 0)
+      throw SolverError(4, "block " + std::to_string(j) + " is not owned by this rank");
+    const BlockDesc &bd = blk_[l];
+    if(w == "x") return {&x_, (size_t)bd.voff, (size_t)bd.P};
+    if(w == "dx") return {&dx_, (size_t)bd.voff, (size_t)bd.P};
+    if(w == "c") return {&c_, (size_t)bd.voff, (size_t)bd.P};
+    if(w == "dual_residues") return {&dres_, (size_t)bd.voff, (size_t)bd.P};
+    if(w == "S" || w == "L") return {&S_, (size_t)h_schur_[l].off, (size_t)bd.P * bd.P};
+    if(w == "BT") return {&BT_, (size_t)h_bt_[l].off, (size_t)bd.P * N_};
+    if(w == "PT") return {&PT_, (size_t)h_bt_[l].off, (size_t)bd.P * N_};
+    const int q = 2 * l + (parity ? 1 : 0);
+    const size_t nn = (size_t)bd.n[parity ? 1 : 0] * bd.n[parity ? 1 : 0], qq = (size_t)bd.m * bd.K * bd.m * bd.K;
+    if(w == "X") return {&X_, (size_t)h_psd_[q].off, nn};
+    if(w == "Y") return {&Y_, (size_t)h_psd_[q].off, nn};
+    if(w == "dX") return {&dX_, (size_t)h_psd_[q].off, nn};
+    if(w == "dY") return {&dY_, (size_t)h_psd_[q].off, nn};
+    if(w == "Xc") return {&Xc_, (size_t)h_psd_[q].off, nn};
+    if(w == "Yc") return {&Yc_, (size_t)h_psd_[q].off, nn};
+    if(w == "primal_residues") return {&PR_, (size_t)h_psd_[q].off, nn};
+    if(w == "AXinv") return {&AX_, (size_t)h_pair_[q].off, qq};
+    if(w == "AY") return {&AY_, (size_t)h_pair_[q].off, qq};
+    throw SolverError(4, "unknown array " + w);
+  }
+  // column-major, newline separated decimals
+  std::string get_array(const std::string &which, int j, int parity) override
+  {
+    const ArrayRef r = locate(which, j, parity);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    std::vector<M> v = download<NL>(*r.a, r.off, r.count);
+    std::string out;
+    for(auto &e : v)
+      {
+        out += mw::to_decimal<NL>(e);
+        out += "\n";
+      }
+    return out;
+  }
+  // checkpoint-style state injection (x, X, y, Y): column-major decimals
+  void set_array(const std::string &which, int j, int parity, const char *txt) override
+  {
+    if(which != "x" && which != "X" && which != "y" && which != "Y")
+      throw SolverError(4, "set_array: only x, X, y, Y can be set");
+    if(which != "y" && local_index(j) < 0)
+      return;
+    const ArrayRef r = locate(which, j, parity);
+    upload<NL>(*r.a, r.off, parse_list(txt, r.count, which.c_str()));
+  }
+
+  // ==========================================================================
+  // operator-level entry points (parity tests call the device arithmetic and the
+  // fixed-point syrk kernel in isolation through the C ABI)
+  // ==========================================================================
+  std::string op_scalar(const std::string &op, const char *a, const char *b) override
+  {
+    int code = op == "add" ? 0 : op == "sub" ? 1 : op == "mul" ? 2 : op == "div" ? 3 : op == "sqrt" ? 4 : -1;
+    if(code < 0)
+      throw SolverError(4, "op_scalar: unknown op " + op);
+    DevArray io;
+    io.alloc(3, NL);
+    upload<NL>(io, 0, std::vector<M>{mw::from_decimal<NL>(a), mw::from_decimal<NL>(b)});
+    mw::Ptr p = io.ptr();
+    foreach(1, [=] __device__(size_t) {
+      const M x = mw::load<NL>(p, 0), y = mw::load<NL>(p, 1);
+      M r;
+      switch(code)
+        {
+        case 0: r = mw::add(x, y); break;
+        case 1: r = mw::sub(x, y); break;
+        case 2: r = mw::mul(x, y); break;
+        case 3: r = mw::div(x, y); break;
+        default: r = mw::sqrt(x); break;
+        }
+      mw::store<NL>(p, 2, r);
+    });
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return mw::to_decimal<NL>(download<NL>(io, 2, 1)[0]);
+  }
+
+  // Exact integer syrk of a rows x cols integer matrix (column-major decimal
+  // integers, |v| < 2^(32 FX)); returns the lower triangle of P^T P (cols x cols,
+  // column-major, upper part zero) as decimal integers.  Same kernel as syrk_Q.
+  std::string op_int_syrk(int rows, int cols, const char *txt) override
+  {
+    std::vector<std::pair<const char *, const char *>> tok;
+    split_numbers(txt, tok);
+    if((int)tok.size() != rows * cols)
+      throw SolverError(4, "op_int_syrk: wrong element count");
+    const size_t cnt = (size_t)rows * cols;
+    std::vector<uint32_t> h(cnt * (FX + 1), 0);
+    for(int c = 0; c < cols; ++c)
+      for(int r = 0; r < rows; ++r)
+        {
+          const char *s = tok[(size_t)c * rows + r].first, *e = tok[(size_t)c * rows + r].second;
+          bool negative = false;
+          if(*s == '-')
+            {
+              negative = true;
+              ++s;
+            }
+          mw::BigNat n;
+          for(; s < e; ++s)
+            {
+              if(*s < '0' || *s > '9')
+                throw SolverError(4, "op_int_syrk: not an integer");
+              if(n.w.empty())
+                {
+                  if(*s != '0')
+                    n.w.push_back((uint32_t)(*s - '0'));
+                }
+              else
+                n.mul_small(10, (uint32_t)(*s - '0'));
+            }
+          if(n.w.size() > (size_t)FX)
+            throw SolverError(4, "op_int_syrk: |value| >= 2^(32*FX)");
+          const size_t idx = (size_t)r * cols + c; // fx element (r, n) at r*N + n
+          for(size_t k = 0; k < n.w.size(); ++k)
+            h[(k + 1) * cnt + idx] = n.w[k];
+          h[idx] = (negative && !n.w.empty()) ? 1u : 0u;
+        }
+    DevBuf<uint32_t> fx, acc;
+    fx.upload(h);
+    const size_t as = (size_t)cols * cols;
+    acc.alloc(as * ACCW);
+    const unsigned tiles = cdiv(cols, 16);
+    launch(k_syrk_fx<FX, SYRK_RB>, dim3(tiles * (tiles + 1) / 2), dim3(WG), stream_, (const uint32_t *)fx.p, cnt, (size_t)0, (size_t)rows,
+           cols, acc.p, as, 0);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    std::vector<uint32_t> a = acc.download();
+    std::string out;
+    for(int j = 0; j < cols; ++j)
+      for(int i = 0; i < cols; ++i)
+        {
+          const size_t idx = (size_t)i + (size_t)j * cols;
+          if(i < j)
+            {
+              out += "0\n";
+              continue;
+            }
+          mw::BigNat n;
+          n.w.resize(ACCW);
+          for(int k = 0; k < ACCW; ++k)
+            n.w[k] = a[(size_t)k * as + idx];
+          const bool negative = n.w[ACCW - 1] >> 31;
+          if(negative)
+            {
+              uint64_t carry = 1;
+              for(auto &w : n.w)
+                {
+                  const uint64_t s = (uint64_t)(~w) + carry;
+                  w = (uint32_t)s;
+                  carry = s >> 32;
+                }
+            }
+          n.trim();
+          std::string dig;
+          while(!n.is_zero())
+            {
+              uint32_t rem = n.div_small(1000000000u);
+              for(int k = 0; k < 9; ++k)
+                {
+                  dig.push_back((char)('0' + rem % 10));
+                  rem /= 10;
+                }
+            }
+          while(!dig.empty() && dig.back() == '0')
+            dig.pop_back();
+          if(dig.empty())
+            dig = "0";
+          else if(negative)
+            dig.push_back('-');
+          out.append(dig.rbegin(), dig.rend());
+          out += "\n";
+        }
+    return out;
+  }
+};
+
+// one factory per compiled limb count (solver_nl.hip is built once per SDPB_NL)
+SolverBase *make_solver_6(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+SolverBase *make_solver_10(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+SolverBase *make_solver_16(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+SolverBase *make_solver_18(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+SolverBase *make_solver_24(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+SolverBase *make_solver_26(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+SolverBase *make_solver_34(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+} // namespace sdpb

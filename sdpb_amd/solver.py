@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference's SDP_Solver interface over the C ABI.
+
+`SDPSolver` plays the role of `SDP_Solver` (src/sdp_solve/SDP_Solver.hxx:28-112):
+construct it from an SDP + Solver_Parameters, call `run()` (the loop of
+SDP_Solver::run, run/run.cxx:322-467) or `iterate()` for a single pass of the loop
+body; per-iteration records carry the keys of out/iterations.json
+(print_iteration.cxx:91-104).  All arithmetic happens in HIP kernels behind
+include/sdpb_hip.h; this module only moves strings and never computes.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import time
+from typing import Callable, Dict, List, Optional
+
+from .sdp_io import SDP, block_text
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libsdpb_hip.so")
+
+ITERATION_KEYS = ["mu", "P-obj", "D-obj", "gap", "P-err", "p-err", "D-err", "R-err",
+                  "P-step", "D-step", "beta", "Q_cond_number", "max_block_cond_number"]
+PARAM_NAMES = ["dualityGapThreshold", "primalErrorThreshold", "dualErrorThreshold",
+               "initialMatrixScalePrimal", "initialMatrixScaleDual", "feasibleCenteringParameter",
+               "infeasibleCenteringParameter", "stepLengthReduction", "maxComplementarity",
+               "minPrimalStep", "minDualStep"]
+FLAG_NAMES = ["maxIterations", "findPrimalFeasible", "findDualFeasible",
+              "detectPrimalFeasibleJump", "detectDualFeasibleJump"]
+
+ALLREDUCE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+ALLGATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
+class _Collectives(ctypes.Structure):
+    _fields_ = [("allreduce_sum_u64", ALLREDUCE_CB), ("allgather_bytes", ALLGATHER_CB),
+                ("user", ctypes.c_void_p)]
+
+
+class SDPBError(RuntimeError):
+    """Mirrors the reference's RUNTIME_ERROR; .code is the C-ABI return code."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+_libs: Dict[str, ctypes.CDLL] = {}
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    path = path or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise SDPBError(3, f"{path} not found: build the HIP extension first "
+                           "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    L = ctypes.CDLL(path)
+    c_int_p = ctypes.POINTER(ctypes.c_int)
+    size_p = ctypes.POINTER(ctypes.c_size_t)
+    L.sdpb_hip_create.argtypes = [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.sdpb_hip_destroy.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_destroy.restype = None
+    L.sdpb_hip_last_error.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_last_error.restype = ctypes.c_char_p
+    L.sdpb_hip_set_param.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.sdpb_hip_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 4
+    L.sdpb_hip_set_block.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_char_p] * 4
+    L.sdpb_hip_set_objective.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.sdpb_hip_init_state.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_iterate.argtypes = [ctypes.c_void_p, c_int_p]
+    L.sdpb_hip_terminate_reason.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_terminate_string.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_terminate_string.restype = ctypes.c_char_p
+    L.sdpb_hip_get_scalar.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, size_p]
+    L.sdpb_hip_get_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_char_p, ctypes.c_size_t, size_p]
+    L.sdpb_hip_set_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    L.sdpb_hip_block_owner.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sdpb_hip_limbs.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_set_collectives.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Collectives)]
+    L.sdpb_hip_timers.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, size_p]
+    L.sdpb_hip_plan_blocks.argtypes = [ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int, c_int_p]
+    L.sdpb_hip_op_scalar.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 4 + [ctypes.c_size_t, size_p]
+    L.sdpb_hip_op_int_syrk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                       ctypes.c_char_p, ctypes.c_size_t, size_p]
+    ull_p = ctypes.POINTER(ctypes.c_ulonglong)
+    L.sdpb_hip_host_encode_u64.argtypes = [ctypes.c_char_p, ctypes.c_int, ull_p]
+    L.sdpb_hip_host_decode_u64.argtypes = [ull_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, size_p]
+    _libs[path] = L
+    return L
+
+
+def plan_blocks(dims: List[int], num_points: List[int], N: int, world_size: int,
+                lib_path: Optional[str] = None) -> List[int]:
+    """Block -> rank assignment (pure host logic, no GPU needed)."""
+    L = load_library(lib_path)
+    J = len(dims)
+    out = (ctypes.c_int * J)()
+    rc = L.sdpb_hip_plan_blocks(J, (ctypes.c_int * J)(*dims), (ctypes.c_int * J)(*num_points), N, world_size, out)
+    if rc:
+        raise SDPBError(rc, "sdpb_hip_plan_blocks failed")
+    return list(out)
+
+
+class SDPSolver:
+    def __init__(self, sdp: SDP, precision: int, params: Optional[dict] = None, device: int = -1,
+                 rank: int = 0, world_size: int = 1, lib_path: Optional[str] = None,
+                 upload_all_blocks: bool = True):
+        self.L = load_library(lib_path)
+        self.sdp = sdp
+        self.precision = precision
+        self.rank, self.world_size = rank, world_size
+        J = sdp.J
+        h = ctypes.c_void_p()
+        rc = self.L.sdpb_hip_create(precision, J, (ctypes.c_int * J)(*sdp.dims),
+                                    (ctypes.c_int * J)(*sdp.num_points), sdp.N, device, rank, world_size,
+                                    ctypes.byref(h))
+        if rc:
+            raise SDPBError(rc, self.L.sdpb_hip_last_error(None).decode())
+        self.h = h
+        self._cb_keepalive = None
+        self.set_params(params or {})
+        for j, blk in enumerate(sdp.blocks):
+            if upload_all_blocks or self.block_owner(j) == rank:
+                self._chk(self.L.sdpb_hip_set_block(self.h, j, *block_text(blk)))
+        self._chk(self.L.sdpb_hip_set_objective(self.h, " ".join(sdp.b).encode(), sdp.constant.encode()))
+        self._chk(self.L.sdpb_hip_init_state(self.h))
+        self.iteration = 0
+        self.terminated = False
+
+    # -- plumbing ---------------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            raise SDPBError(rc, self.L.sdpb_hip_last_error(self.h).decode())
+
+    def _string(self, fn, *args) -> str:
+        need = ctypes.c_size_t(0)
+        buf = ctypes.create_string_buffer(4096)
+        rc = fn(self.h, *args, buf, len(buf), ctypes.byref(need))
+        if rc == 4 and need.value > len(buf):
+            buf = ctypes.create_string_buffer(need.value)
+            rc = fn(self.h, *args, buf, len(buf), ctypes.byref(need))
+        self._chk(rc)
+        return buf.value.decode()
+
+    def set_params(self, params: dict):
+        flags = dict(maxIterations=500, findPrimalFeasible=0, findDualFeasible=0,
+                     detectPrimalFeasibleJump=0, detectDualFeasibleJump=0)
+        for k, v in params.items():
+            if k in flags:
+                flags[k] = int(v)
+            elif k in PARAM_NAMES:
+                self._chk(self.L.sdpb_hip_set_param(self.h, k.encode(), str(v).encode()))
+            else:
+                raise SDPBError(4, f"unknown solver parameter {k}")
+        self._chk(self.L.sdpb_hip_set_flags(self.h, flags["maxIterations"], flags["findPrimalFeasible"],
+                                            flags["findDualFeasible"], flags["detectPrimalFeasibleJump"],
+                                            flags["detectDualFeasibleJump"]))
+
+    def set_collectives(self, allreduce_sum_u64: Callable, allgather_bytes: Callable):
+        """Register the cross-GPU exchange callbacks (device pointers in, 0 = ok out)."""
+        cb = _Collectives(ALLREDUCE_CB(lambda user, p, n: int(allreduce_sum_u64(p, n))),
+                          ALLGATHER_CB(lambda user, s, r, n: int(allgather_bytes(s, r, n))), None)
+        self._cb_keepalive = cb
+        self._chk(self.L.sdpb_hip_set_collectives(self.h, ctypes.byref(cb)))
+
+    # -- SDP_Solver surface -------------------------------------------------------
+    def block_owner(self, j: int) -> int:
+        return self.L.sdpb_hip_block_owner(self.h, j)
+
+    @property
+    def limbs(self) -> int:
+        return self.L.sdpb_hip_limbs(self.h)
+
+    def iterate(self) -> bool:
+        """One pass of the loop body of SDP_Solver::run; True when the loop ends."""
+        t = ctypes.c_int(0)
+        self._chk(self.L.sdpb_hip_iterate(self.h, ctypes.byref(t)))
+        self.iteration += 1
+        self.terminated = bool(t.value)
+        return self.terminated
+
+    def scalar(self, name: str) -> str:
+        return self._string(self.L.sdpb_hip_get_scalar, name.encode())
+
+    def scalars(self) -> dict:
+        d = {k: self.scalar(k) for k in ITERATION_KEYS}
+        d["block_name"] = self.scalar("block_name")
+        return d
+
+    def array(self, which: str, j: int = 0, parity: int = 0) -> List[str]:
+        return self._string(self.L.sdpb_hip_get_array, which.encode(), j, parity).split()
+
+    def set_array(self, which: str, values: List[str], j: int = 0, parity: int = 0):
+        self._chk(self.L.sdpb_hip_set_array(self.h, which.encode(), j, parity, " ".join(values).encode()))
+
+    @property
+    def terminate_reason(self) -> str:
+        return self.L.sdpb_hip_terminate_string(self.h).decode()
+
+    def timers(self) -> dict:
+        return json.loads(self._string(self.L.sdpb_hip_timers))
+
+    def run(self, max_runtime: float = float("inf"), on_iteration: Optional[Callable] = None) -> str:
+        """SDP_Solver::run: iterate until a terminate reason is set; returns it."""
+        start = time.time()
+        while True:
+            if self.iterate():
+                return self.terminate_reason
+            rec = {"iteration": self.iteration, **self.scalars()}
+            if on_iteration:
+                on_iteration(rec)
+            if time.time() - start >= max_runtime:
+                return "maxRuntime exceeded"
+
+    def out_txt(self) -> dict:
+        """The keys of out.txt (src/sdpb/save_solution.cxx:32-37)."""
+        return {"terminateReason": self.terminate_reason,
+                **{k: self.scalar(k) for k in ("primalObjective", "dualObjective", "dualityGap",
+                                               "primalError", "dualError")}}
+
+    # -- operator-level entry points -----------------------------------------------
+    def op_scalar(self, op: str, a, b="0") -> str:
+        return self._string(self.L.sdpb_hip_op_scalar, op.encode(), str(a).encode(), str(b).encode())
+
+    def op_int_syrk(self, rows: int, cols: int, ints_colmajor) -> List[int]:
+        txt = " ".join(str(v) for v in ints_colmajor).encode()
+        return [int(s) for s in self._string(self.L.sdpb_hip_op_int_syrk, rows, cols, txt).split()]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sdpb_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,63 @@
+"""TEST INFRASTRUCTURE ONLY: build the CPU-emulated twin of libsdpb_hip.so.
+
+Compiles the *unmodified* sdpb_amd/csrc sources with g++ against tests/emu/hip_emu.hpp
+(a stand-in for <hip/hip_runtime.h>) so the host logic and the kernels' index arithmetic
+can be exercised without a GPU by `pytest -m "not gpu"`.  Never used by the product,
+bench.py or smoke(); see hip_emu.hpp.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "sdpb_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
+LIMBS = (6, 10, 16, 18, 24, 26, 34)
+CXX = os.environ.get("CXX", "g++")
+FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-x", "c++", "-I" + os.path.join(HERE, "include"),
+         "-Wno-unknown-pragmas", "-Wno-attributes"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout[-4000:] + r.stderr[-8000:])
+        raise RuntimeError("emu build failed")
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu.hpp"),
+                                                                 os.path.join(HERE, "hip_emu.cpp"),
+                                                                 os.path.join(ROOT, "include", "sdpb_hip.h")]
+    jobs, objs = [], []
+    for nl in LIMBS:
+        obj = os.path.join(OUT, f"solver_{nl}.o")
+        objs.append(obj)
+        if force or _stale(obj, deps):
+            jobs.append([CXX, *FLAGS, f"-DSDPB_NL={nl}", "-c", os.path.join(CSRC, "solver_nl.hip"), "-o", obj])
+    for src, name in ((os.path.join(CSRC, "capi.hip"), "capi.o"), (os.path.join(HERE, "hip_emu.cpp"), "hip_emu.o")):
+        obj = os.path.join(OUT, name)
+        objs.append(obj)
+        if force or _stale(obj, deps):
+            jobs.append([CXX, *FLAGS, "-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or not os.path.exists(LIB):
+        _run([CXX, "-shared", "-fPIC", "-fopenmp", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))
