@@ -59,6 +59,10 @@ int sdpb_hip_set_flags(sdpb_hip_ctx *ctx, long max_iterations, int find_primal_f
  * another rank are accepted and ignored, so every rank may be fed the whole SDP. */
 int sdpb_hip_set_block(sdpb_hip_ctx *ctx, int j, const char *bilinear_bases_even, const char *bilinear_bases_odd,
                        const char *B, const char *c);
+/* Same block, with B (row-major P x N) and c passed as IEEE doubles (converted exactly):
+ * bulk path for inputs whose entries are dyadic rationals (synthetic benchmarks). */
+int sdpb_hip_set_block_f64(sdpb_hip_ctx *ctx, int j, const char *bilinear_bases_even, const char *bilinear_bases_odd,
+                           const double *B, const double *c);
 /* objectives.json: "b" and "constant" (src/sdp_solve/SDP/read_objectives.cxx:22-36). */
 int sdpb_hip_set_objective(sdpb_hip_ctx *ctx, const char *b, const char *constant);
 

@@ -51,6 +51,8 @@ def lib():
         L.orc_get_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         L.orc_int_syrk.restype = ctypes.c_char_p
         L.orc_int_syrk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+        L.orc_parse_exact.restype = ctypes.c_char_p
+        L.orc_parse_exact.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.orc_scalar_op.restype = ctypes.c_char_p
         L.orc_scalar_op.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 3
         _lib = L
@@ -116,6 +118,17 @@ class Oracle:
     def int_syrk(self, rows, cols, ints_colmajor):
         txt = " ".join(str(v) for v in ints_colmajor).encode()
         return [int(s) for s in self.L.orc_int_syrk(self.h, rows, cols, txt).decode().split()]
+
+    def parse_exact(self, value, prec_bits=64) -> str:
+        """Exact decimal of the number GMP obtains when parsing `value` at prec_bits."""
+        n, k = self.L.orc_parse_exact(self.h, str(value).encode(), prec_bits).decode().split()
+        n, k = int(n), int(k)
+        sign = "-" if n < 0 else ""
+        digits = str(abs(n) * 5 ** k)  # n / 2^k = n 5^k / 10^k
+        if k == 0:
+            return sign + digits
+        digits = digits.rjust(k + 1, "0")
+        return sign + digits[:-k] + "." + digits[-k:]
 
     def scalar_op(self, op, a, b="0"):
         return self.L.orc_scalar_op(self.h, op.encode(), str(a).encode(), str(b).encode()).decode()

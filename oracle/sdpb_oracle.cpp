@@ -341,8 +341,11 @@ void gemm_nn(const F &alpha, const Mat &A, const Mat &B, const F &beta, Mat &C)
 }
 
 // Smallest eigenvalue of a symmetric matrix (min_eigenvalue.cxx:8-33 calls
-// El::HermitianEig and takes El::Min; only the value is used).  Cyclic Jacobi
-// rotations converge to every eigenvalue to working precision.
+// El::HermitianEig and takes El::Min; only the value is used).  Like Elemental this
+// reduces to tridiagonal form with Householder reflections (4n^3/3 flops) and then
+// finds the eigenvalues of the tridiagonal matrix — here with the implicit QL
+// iteration (the published EISPACK tred1/tql1 algorithms; Elemental's
+// divide-and-conquer yields the same eigenvalues to working precision).
 F min_eigenvalue_sym(Mat A)
 {
   const int n = A.h;
@@ -352,62 +355,124 @@ F min_eigenvalue_sym(Mat A)
   if(n == 1)
     return A(0, 0);
   const mp_bitcnt_t prec = mpf_get_prec(A(0, 0).v);
-  F off, diag, eps, t, c, s, theta, tmp, tmp2, one(1L), two(2L), app, apq, aqq;
-  mpf_set_ui(eps.v, 1);
-  mpf_div_2exp(eps.v, eps.v, 2 * prec - 20); // off/diag < 2^-(prec-10): eigenvalue error ~ off^2
-  for(int sweep = 0; sweep < 200; ++sweep)
+  std::vector<F> d(n), e(n);
+  F f, g, h, hh, tmp, zero(0L), one(1L), two(2L);
+  // Householder reduction, lower triangle referenced
+  for(int i = n - 1; i >= 1; --i)
     {
-      mpf_set_ui(off.v, 0);
-      mpf_set_ui(diag.v, 0);
-      for(int j = 0; j < n; ++j)
-        for(int i = 0; i < n; ++i)
-          {
-            tmp = A(i, j) * A(i, j);
-            if(i == j)
-              diag += tmp;
-            else
-              off += tmp;
-          }
-      tmp = diag * eps;
-      if(off.is_zero() || off < tmp)
-        break;
-      for(int p = 0; p < n - 1; ++p)
-        for(int q = p + 1; q < n; ++q)
-          {
-            apq = A(p, q);
-            if(apq.is_zero())
-              continue;
-            app = A(p, p);
-            aqq = A(q, q);
-            theta = (aqq - app) / (two * apq);
-            // t = sgn(theta) / (|theta| + sqrt(theta^2+1))
-            tmp = fsqrt(theta * theta + one);
-            tmp = fabs_(theta) + tmp;
-            t = one / tmp;
-            if(mpf_sgn(theta.v) < 0)
-              t = -t;
-            c = one / fsqrt(t * t + one);
-            s = t * c;
-            for(int k = 0; k < n; ++k)
-              {
-                tmp = A(k, p);
-                tmp2 = A(k, q);
-                A(k, p) = c * tmp - s * tmp2;
-                A(k, q) = s * tmp + c * tmp2;
-              }
-            for(int k = 0; k < n; ++k)
-              {
-                tmp = A(p, k);
-                tmp2 = A(q, k);
-                A(p, k) = c * tmp - s * tmp2;
-                A(q, k) = s * tmp + c * tmp2;
-              }
-          }
+      const int l = i - 1;
+      mpf_set_ui(h.v, 0);
+      if(l > 0)
+        {
+          for(int k = 0; k <= l; ++k)
+            fma_(h, A(i, k), A(i, k), tmp);
+          if(h.is_zero())
+            e[i] = A(i, l);
+          else
+            {
+              f = A(i, l);
+              g = fsqrt(h);
+              if(mpf_sgn(f.v) >= 0)
+                g = -g;
+              e[i] = g;
+              h -= f * g;
+              A(i, l) = f - g;
+              mpf_set_ui(f.v, 0);
+              for(int j = 0; j <= l; ++j)
+                {
+                  mpf_set_ui(g.v, 0);
+                  for(int k = 0; k <= j; ++k)
+                    fma_(g, A(j, k), A(i, k), tmp);
+                  for(int k = j + 1; k <= l; ++k)
+                    fma_(g, A(k, j), A(i, k), tmp);
+                  e[j] = g / h;
+                  fma_(f, e[j], A(i, j), tmp);
+                }
+              hh = f / (h + h);
+              for(int j = 0; j <= l; ++j)
+                {
+                  f = A(i, j);
+                  g = e[j] - hh * f;
+                  e[j] = g;
+                  for(int k = 0; k <= j; ++k)
+                    {
+                      fms_(A(j, k), f, e[k], tmp);
+                      fms_(A(j, k), g, A(i, k), tmp);
+                    }
+                }
+            }
+        }
+      else
+        e[i] = A(i, l);
     }
-  result = A(0, 0);
+  for(int i = 0; i < n; ++i)
+    d[i] = A(i, i);
+  // implicit QL on (d, e)
   for(int i = 1; i < n; ++i)
-    if(A(i, i) < result)
-      result = A(i, i);
+    e[i - 1] = e[i];
+  mpf_set_ui(e[n - 1].v, 0);
+  F eps(1L), dd, r, sn, c, p, bb;
+  mpf_div_2exp(eps.v, eps.v, prec + 8);
+  for(int l = 0; l < n; ++l)
+    {
+      int iter = 0, m;
+      do
+        {
+          for(m = l; m < n - 1; ++m)
+            {
+              dd = fabs_(d[m]) + fabs_(d[m + 1]);
+              tmp = eps * dd;
+              if(!(fabs_(e[m]) > tmp))
+                break;
+            }
+          if(m != l)
+            {
+              if(++iter > 100000)
+                throw std::runtime_error("oracle: tridiagonal QL did not converge");
+              g = (d[l + 1] - d[l]) / (two * e[l]);
+              r = fsqrt(g * g + one);
+              if(mpf_sgn(g.v) < 0)
+                r = -r;
+              g = d[m] - d[l] + e[l] / (g + r);
+              sn = one;
+              c = one;
+              mpf_set_ui(p.v, 0);
+              int i;
+              bool underflow = false;
+              for(i = m - 1; i >= l; --i)
+                {
+                  f = sn * e[i];
+                  bb = c * e[i];
+                  r = fsqrt(f * f + g * g);
+                  e[i + 1] = r;
+                  if(r.is_zero())
+                    {
+                      d[i + 1] -= p;
+                      mpf_set_ui(e[m].v, 0);
+                      underflow = true;
+                      break;
+                    }
+                  sn = f / r;
+                  c = g / r;
+                  g = d[i + 1] - p;
+                  r = (d[i] - g) * sn + two * c * bb;
+                  p = sn * r;
+                  d[i + 1] = g + p;
+                  g = c * r - bb;
+                }
+              if(underflow)
+                continue;
+              d[l] -= p;
+              e[l] = g;
+              mpf_set_ui(e[m].v, 0);
+            }
+        }
+      while(m != l);
+    }
+  result = d[0];
+  for(int i = 1; i < n; ++i)
+    if(d[i] < result)
+      result = d[i];
   return result;
 }
 
@@ -1580,6 +1645,24 @@ const char *orc_int_syrk(void *h, int rows, int cols, const char *Ptxt)
       }
   mpz_clear(acc);
   o->strbuf = ss.str();
+  return o->strbuf.c_str();
+}
+
+// The value GMP gives a decimal string when parsed at `prec_bits` (the reference parses its
+// Solver_Parameters before --precision is applied), as an exact decimal expansion.
+const char *orc_parse_exact(void *h, const char *value, int prec_bits)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  F v = from_str(value, prec_bits ? prec_bits : 0);
+  // exact rational n / 2^k (mpq_set_f is exact); the caller expands it in decimal
+  mpq_t q;
+  mpq_init(q);
+  mpq_set_f(q, v.v);
+  char *num = mpz_get_str(nullptr, 10, mpq_numref(q));
+  const unsigned long k = mpz_sizeinbase(mpq_denref(q), 2) - 1; // denominator is a power of two
+  o->strbuf = std::string(num) + " " + std::to_string(k);
+  free(num);
+  mpq_clear(q);
   return o->strbuf.c_str();
 }
 

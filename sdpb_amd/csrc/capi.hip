@@ -85,15 +85,23 @@ int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const i
       sdpb::SolverBase *s = nullptr;
       // round the request up to the next compiled mantissa width ("GMP will round this
       // up", Solver_Parameters.cxx:26-28)
-      if(want <= 6) s = sdpb::make_solver_6(precision_bits, d, k, N, rank, world_size);
-      else if(want <= 10) s = sdpb::make_solver_10(precision_bits, d, k, N, rank, world_size);
-      else if(want <= 16) s = sdpb::make_solver_16(precision_bits, d, k, N, rank, world_size);
-      else if(want <= 18) s = sdpb::make_solver_18(precision_bits, d, k, N, rank, world_size);
-      else if(want <= 24) s = sdpb::make_solver_24(precision_bits, d, k, N, rank, world_size);
-      else if(want <= 26) s = sdpb::make_solver_26(precision_bits, d, k, N, rank, world_size);
-      else if(want <= 34) s = sdpb::make_solver_34(precision_bits, d, k, N, rank, world_size);
-      else
-        return fail(nullptr, 4, "sdpb_hip_create: precision above 1024 bits is not compiled in");
+      struct Entry
+      {
+        int limbs;
+        sdpb::SolverBase *(*make)(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+      };
+      const Entry table[] = {{6, sdpb::make_solver_6},   {10, sdpb::make_solver_10}, {16, sdpb::make_solver_16},
+                             {18, sdpb::make_solver_18}, {24, sdpb::make_solver_24}, {26, sdpb::make_solver_26},
+                             {34, sdpb::make_solver_34}};
+      for(const Entry &e : table)
+        if(want <= e.limbs && e.make)
+          {
+            s = e.make(precision_bits, d, k, N, rank, world_size);
+            break;
+          }
+      if(!s)
+        return fail(nullptr, 4, "sdpb_hip_create: no compiled mantissa width covers --precision "
+                                   + std::to_string(precision_bits) + " (build all limb counts, see sdpb_amd/build.py)");
       ctx->solver.reset(s);
       *out = ctx.release();
       return 0;
@@ -127,6 +135,10 @@ int sdpb_hip_set_flags(sdpb_hip_ctx *ctx, long max_iterations, int fpf, int fdf,
 int sdpb_hip_set_block(sdpb_hip_ctx *ctx, int j, const char *be, const char *bo, const char *B, const char *c)
 {
   return guarded(ctx, [&] { ctx->solver->set_block(j, be, bo, B, c); });
+}
+int sdpb_hip_set_block_f64(sdpb_hip_ctx *ctx, int j, const char *be, const char *bo, const double *B, const double *c)
+{
+  return guarded(ctx, [&] { ctx->solver->set_block_f64(j, be, bo, B, c); });
 }
 int sdpb_hip_set_objective(sdpb_hip_ctx *ctx, const char *b, const char *constant)
 {

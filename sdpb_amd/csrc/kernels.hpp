@@ -780,18 +780,60 @@ __global__ void __launch_bounds__(WG)
 }
 
 // ---------------------------------------------------------------------------
-// Smallest eigenvalue of a batch of symmetric matrices: cyclic Jacobi with the
-// round-robin parallel ordering, one workgroup per matrix, in place.
-// Replaces El::HermitianEig + El::Min at min_eigenvalue.cxx:8-33.
+// Smallest eigenvalue of a batch of symmetric matrices (in place, lower triangle
+// referenced).  Replaces El::HermitianEig + El::Min at min_eigenvalue.cxx:8-33.
+// Like Elemental: Householder reduction to tridiagonal form (one wavefront per
+// matrix, reductions through LDS), then only the eigenvalue that is needed:
+// lambda_min of the tridiagonal matrix by an fp64 Sturm bisection (a safe starting
+// point below the spectrum) refined with Newton's method on det(T - lambda) in full
+// multi-word precision — monotone from below, quadratically convergent.
 // lam[q] = lambda_min (zero-size matrices write +huge so they never win the MIN).
 // ---------------------------------------------------------------------------
-constexpr int JACOBI_MAX_HALF = 128; // supports n <= 256
-template <int NL> __global__ void __launch_bounds__(WG) k_jacobi_min_eig(Batch A, mw::Ptr lam, int max_sweeps)
+constexpr int EIG_T = 64;      // one wavefront per matrix
+constexpr int EIG_MAX_N = 512; // fp64 staging of the tridiagonal matrix in LDS
+
+template <int NL> __device__ Mw<NL> eig_reduce_sum(const Mw<NL> &v)
+{
+  __shared__ Mw<NL> sm[EIG_T];
+  const int t = threadIdx.x;
+  sm[t] = v;
+  __syncthreads();
+  for(int s = EIG_T / 2; s > 0; s >>= 1)
+    {
+      if(t < s)
+        sm[t] = mw::add(sm[t], sm[t + s]);
+      __syncthreads();
+    }
+  const Mw<NL> r = sm[0];
+  __syncthreads();
+  return r;
+}
+
+// number of eigenvalues of the tridiagonal (a, b2 = offdiag^2) below x, in fp64
+__device__ inline int sturm_count_f64(const double *a, const double *b2, int n, double x)
+{
+  int cnt = 0;
+  double q = a[0] - x;
+  if(q < 0)
+    ++cnt;
+  for(int i = 1; i < n; ++i)
+    {
+      if(q == 0.0)
+        q = 1e-300;
+      q = a[i] - x - b2[i] / q;
+      if(q < 0)
+        ++cnt;
+    }
+  return cnt;
+}
+
+template <int NL> __global__ void __launch_bounds__(EIG_T) k_min_eig(Batch A, Batch D, Batch E, mw::Ptr lam)
 {
   const int q = blockIdx.x;
   const MatDesc d = A.d[q];
+  const size_t od = (size_t)D.d[q].off, oe = (size_t)E.d[q].off;
   const int n = d.rows, t = threadIdx.x;
-  if(n == 0)
+  if(n == 0 || n > EIG_MAX_N)
     {
       if(t == 0)
         {
@@ -801,105 +843,182 @@ template <int NL> __global__ void __launch_bounds__(WG) k_jacobi_min_eig(Batch A
         }
       return;
     }
-  __shared__ Mw<NL> s_c[JACOBI_MAX_HALF], s_s[JACOBI_MAX_HALF];
-  __shared__ int s_p[JACOBI_MAX_HALF], s_q[JACOBI_MAX_HALF], s_rot;
-  const int ne = (n + 1) & ~1, half = ne / 2;
-  for(int sweep = 0; sweep < max_sweeps && n > 1; ++sweep)
+  __shared__ Mw<NL> s_hinv;
+  __shared__ double s_a[EIG_MAX_N], s_b2[EIG_MAX_N];
+  // ---- Householder tridiagonalisation (EISPACK tred1 organisation) -------------
+  for(int i = n - 1; i >= 1; --i)
     {
-      if(t == 0)
-        s_rot = 0;
-      __syncthreads();
-      for(int rd = 0; rd < ne - 1; ++rd)
+      const int l = i - 1;
+      if(l == 0)
         {
-          // phase A: rotation parameters for the pairs of this round
-          for(int k = t; k < half; k += WG)
-            {
-              int pa, pb;
-              if(k == 0)
-                {
-                  pa = ne - 1;
-                  pb = rd;
-                }
-              else
-                {
-                  pa = (rd + k) % (ne - 1);
-                  pb = (rd - k + (ne - 1)) % (ne - 1);
-                }
-              int p = pa < pb ? pa : pb, qq = pa < pb ? pb : pa;
-              Mw<NL> c = mw::from_u32<NL>(1), s = mw::zero<NL>();
-              if(qq >= n)
-                p = -1; // dummy player of an odd-sized matrix
-              else
-                {
-                  const Mw<NL> apq = mat_ld<NL>(A, d, p, qq);
-                  const Mw<NL> app = mat_ld<NL>(A, d, p, p), aqq = mat_ld<NL>(A, d, qq, qq);
-                  // negligible when |apq| < 2^-(32NL-6) sqrt(|app aqq|)
-                  bool rotate = !mw::is_zero(apq);
-                  if(rotate && !mw::is_zero(app) && !mw::is_zero(aqq))
-                    rotate = 2 * apq.e > app.e + aqq.e - 2 * (32 * NL - 6);
-                  if(rotate)
-                    {
-                      const Mw<NL> one = mw::from_u32<NL>(1);
-                      const Mw<NL> theta = mw::div(mw::sub(aqq, app), mw::mul_2exp(apq, 1));
-                      Mw<NL> tt;
-                      if(mw::is_zero(theta))
-                        tt = one;
-                      else
-                        {
-                          const Mw<NL> rt = mw::sqrt(mw::add(mw::mul(theta, theta), one));
-                          tt = mw::rcp(mw::add(mw::abs(theta), rt));
-                          tt.neg = theta.neg;
-                        }
-                      c = mw::rsqrt(mw::add(mw::mul(tt, tt), one));
-                      s = mw::mul(tt, c);
-                      s_rot = 1;
-                    }
-                  else
-                    p = -1;
-                }
-              s_p[k] = p;
-              s_q[k] = qq;
-              s_c[k] = c;
-              s_s[k] = s;
-            }
-          __syncthreads();
-          // phase B: A <- A J (columns p,q)
-          for(int idx = t; idx < half * n; idx += WG)
-            {
-              const int k = idx / n, r = idx % n, p = s_p[k], qq = s_q[k];
-              if(p < 0)
-                continue;
-              const Mw<NL> c = s_c[k], s = s_s[k];
-              const Mw<NL> x = mat_ld<NL>(A, d, r, p), y = mat_ld<NL>(A, d, r, qq);
-              mat_st<NL>(A, d, r, p, mw::sub(mw::mul(c, x), mw::mul(s, y)));
-              mat_st<NL>(A, d, r, qq, mw::add(mw::mul(s, x), mw::mul(c, y)));
-            }
-          __syncthreads();
-          // phase C: A <- J^T A (rows p,q)
-          for(int idx = t; idx < half * n; idx += WG)
-            {
-              const int k = idx / n, cc = idx % n, p = s_p[k], qq = s_q[k];
-              if(p < 0)
-                continue;
-              const Mw<NL> c = s_c[k], s = s_s[k];
-              const Mw<NL> x = mat_ld<NL>(A, d, p, cc), y = mat_ld<NL>(A, d, qq, cc);
-              mat_st<NL>(A, d, p, cc, mw::sub(mw::mul(c, x), mw::mul(s, y)));
-              mat_st<NL>(A, d, qq, cc, mw::add(mw::mul(s, x), mw::mul(c, y)));
-            }
-          __syncthreads();
+          if(t == 0)
+            mw::store<NL>(E.p, oe + i, mat_ld<NL>(A, d, i, l));
+          continue;
         }
-      const int rot = s_rot;
+      Mw<NL> part = mw::zero<NL>();
+      for(int k = t; k <= l; k += EIG_T)
+        {
+          const Mw<NL> a = mat_ld<NL>(A, d, i, k);
+          part = mw::fma(a, a, part);
+        }
+      const Mw<NL> h0 = eig_reduce_sum<NL>(part);
+      if(mw::is_zero(h0))
+        {
+          if(t == 0)
+            mw::store<NL>(E.p, oe + i, mat_ld<NL>(A, d, i, l));
+          continue;
+        }
+      if(t == 0)
+        {
+          const Mw<NL> f = mat_ld<NL>(A, d, i, l);
+          Mw<NL> g = mw::sqrt(h0);
+          if(!f.neg)
+            g = mw::neg(g);
+          mw::store<NL>(E.p, oe + i, g);
+          const Mw<NL> h = mw::sub(h0, mw::mul(f, g));
+          mat_st<NL>(A, d, i, l, mw::sub(f, g));
+          s_hinv = mw::rcp(h);
+        }
       __syncthreads();
-      if(!rot)
+      const Mw<NL> hinv = s_hinv;
+      part = mw::zero<NL>();
+      for(int j = t; j <= l; j += EIG_T)
+        {
+          Mw<NL> g = mw::zero<NL>();
+          for(int k = 0; k <= j; ++k)
+            g = mw::fma(mat_ld<NL>(A, d, j, k), mat_ld<NL>(A, d, i, k), g);
+          for(int k = j + 1; k <= l; ++k)
+            g = mw::fma(mat_ld<NL>(A, d, k, j), mat_ld<NL>(A, d, i, k), g);
+          const Mw<NL> ej = mw::mul(g, hinv);
+          mw::store<NL>(E.p, oe + j, ej);
+          part = mw::fma(ej, mat_ld<NL>(A, d, i, j), part);
+        }
+      const Mw<NL> f = eig_reduce_sum<NL>(part);
+      const Mw<NL> hh = mw::mul_2exp(mw::mul(f, hinv), -1);
+      for(int j = t; j <= l; j += EIG_T)
+        mw::store<NL>(E.p, oe + j, mw::sub(mw::load<NL>(E.p, oe + j), mw::mul(hh, mat_ld<NL>(A, d, i, j))));
+      __syncthreads();
+      const int w = l + 1;
+      for(int idx = t; idx < w * w; idx += EIG_T)
+        {
+          const int j = idx / w, k = idx % w;
+          if(k > j)
+            continue;
+          Mw<NL> v = mat_ld<NL>(A, d, j, k);
+          v = mw::fms(mat_ld<NL>(A, d, i, j), mw::load<NL>(E.p, oe + k), v);
+          v = mw::fms(mw::load<NL>(E.p, oe + j), mat_ld<NL>(A, d, i, k), v);
+          mat_st<NL>(A, d, j, k, v);
+        }
+      __syncthreads();
+    }
+  __syncthreads();
+  // diagonal, squared off-diagonal, common binary scale for the fp64 image
+  __shared__ int s_emax;
+  if(t == 0)
+    s_emax = mw::EZERO;
+  __syncthreads();
+  for(int i = t; i < n; i += EIG_T)
+    {
+      const Mw<NL> di = mat_ld<NL>(A, d, i, i);
+      mw::store<NL>(D.p, od + i, di);
+      int e = di.e;
+      if(i >= 1)
+        {
+          const Mw<NL> ei = mw::load<NL>(E.p, oe + i);
+          e = ei.e > e ? ei.e : e;
+        }
+      atomicMax(&s_emax, e);
+    }
+  __syncthreads();
+  const int emax = s_emax;
+  for(int i = t; i < n; i += EIG_T)
+    {
+      s_a[i] = mw::to_double(mw::mul_2exp(mw::load<NL>(D.p, od + i), -emax));
+      double b = 0.0;
+      if(i >= 1)
+        {
+          const Mw<NL> ei = mw::load<NL>(E.p, oe + i);
+          b = mw::to_double(mw::mul_2exp(ei, -emax));
+          mw::store<NL>(E.p, oe + i, mw::mul(ei, ei)); // E now holds offdiag^2
+        }
+      s_b2[i] = b * b;
+    }
+  __syncthreads();
+  if(t != 0)
+    return;
+  if(n == 1)
+    {
+      mw::store<NL>(lam, q, mw::load<NL>(D.p, od));
+      return;
+    }
+  // ---- fp64: Gershgorin bounds + bisection for the smallest eigenvalue -------------
+  double lo = 1e300, hi = -1e300;
+  for(int i = 0; i < n; ++i)
+    {
+      const double r = (i >= 1 ? mw::host_device_sqrt(s_b2[i]) : 0.0) + (i + 1 < n ? mw::host_device_sqrt(s_b2[i + 1]) : 0.0);
+      lo = s_a[i] - r < lo ? s_a[i] - r : lo;
+      hi = s_a[i] + r > hi ? s_a[i] + r : hi;
+    }
+  const double span = (hi - lo) > 0 ? (hi - lo) : 1.0;
+  double blo = lo - 1e-9 * span, bhi = hi + 1e-9 * span;
+  for(int it = 0; it < 80; ++it)
+    {
+      const double mid = 0.5 * (blo + bhi);
+      if(sturm_count_f64(s_a, s_b2, n, mid) >= 1)
+        bhi = mid;
+      else
+        blo = mid;
+    }
+  // safely below lambda_min of the exact tridiagonal matrix
+  const double start = blo - 1e-10 * span - 1e-300;
+  Mw<NL> x = mw::mul_2exp(mw::from_double<NL>(start), emax);
+  // ---- multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i -----------
+  const Mw<NL> minus_one = mw::from_i32<NL>(-1);
+  Mw<NL> prev = x;
+  for(int it = 0; it < 200; ++it)
+    {
+      Mw<NL> S = mw::zero<NL>(), inv = mw::zero<NL>(), tq = mw::zero<NL>();
+      bool overshoot = false;
+      for(int i = 0; i < n; ++i)
+        {
+          Mw<NL> qi = mw::sub(mw::load<NL>(D.p, od + i), x), qp = minus_one;
+          if(i >= 1)
+            {
+              const Mw<NL> u = mw::mul(mw::load<NL>(E.p, oe + i), inv);
+              qi = mw::sub(qi, u);
+              qp = mw::add(minus_one, mw::mul(u, tq));
+            }
+          if(qi.neg || mw::is_zero(qi))
+            {
+              overshoot = true;
+              break;
+            }
+          inv = mw::rcp(qi);
+          tq = mw::mul(qp, inv);
+          S = mw::add(S, tq);
+        }
+      if(overshoot)
+        {
+          // cannot happen from below in exact arithmetic; retreat halfway
+          x = mw::mul_2exp(mw::add(x, prev), -1);
+          if(mw::cmp(x, prev) == 0)
+            {
+              Mw<NL> back = mw::abs(x);
+              back.e -= 32 * NL - 8;
+              x = mw::sub(x, back);
+              prev = x;
+            }
+          continue;
+        }
+      if(mw::is_zero(S))
+        break;
+      const Mw<NL> delta = mw::neg(mw::rcp(S));
+      prev = x;
+      x = mw::add(x, delta);
+      if(mw::is_zero(delta) || mw::is_zero(x) || delta.e < x.e - 24 * NL)
         break;
     }
-  if(t == 0)
-    {
-      Mw<NL> mn = mat_ld<NL>(A, d, 0, 0);
-      for(int i = 1; i < n; ++i)
-        mn = mw::min(mn, mat_ld<NL>(A, d, i, i));
-      mw::store<NL>(lam, q, mn);
-    }
+  mw::store<NL>(lam, q, x);
 }
 
 // (max diag / min diag) per matrix: cholesky_condition_number.hxx:8-37 without the

@@ -411,34 +411,78 @@ template <int NL> MW_HD Mw<NL> fms(const Mw<NL> &a, const Mw<NL> &b, const Mw<NL
   return add(acc, neg(mul(a, b)));
 }
 
-// ---- reciprocal, division, square root (Newton from a double seed) ---------
-template <int NL> constexpr int newton_iters()
+// ---- reciprocal, division, square root ---------------------------------------
+// Newton iterations with precision doubling: the seed comes from fp64, every
+// further step runs at (roughly) twice the limb count of the previous one, so a
+// reciprocal costs ~3 full-width multiplications and an inverse square root ~4.5
+// instead of 2 resp. 3 per iteration at full width.
+template <int NH, int NL> MW_HD Mw<NH> narrow(const Mw<NL> &a)
 {
-  // seed ~ 2^-50 relative; each step squares the error
-  int bits = 50, it = 0;
-  while(bits < 32 * NL + 2)
-    {
-      bits = 2 * bits - 2;
-      ++it;
-    }
-  return it;
+  Mw<NH> r;
+#pragma unroll
+  for(int i = 0; i < NH; ++i)
+    r.m[i] = a.m[NL - NH + i];
+  r.e = a.e;
+  r.neg = a.neg;
+  return r;
 }
+template <int NL, int NH> MW_HD Mw<NL> widen(const Mw<NH> &a)
+{
+  Mw<NL> r;
+#pragma unroll
+  for(int i = 0; i < NL - NH; ++i)
+    r.m[i] = 0;
+#pragma unroll
+  for(int i = 0; i < NH; ++i)
+    r.m[NL - NH + i] = a.m[i];
+  r.e = a.e;
+  r.neg = a.neg;
+  return r;
+}
+
+// 1/man for man in [0.5,1) (e = 0, positive), accurate to ~32*NL-3 bits
+template <int NL> struct RcpMant
+{
+  static MW_HD Mw<NL> run(const Mw<NL> &man)
+  {
+    constexpr int NH = NL / 2 + 1;
+    const Mw<NL> r0 = widen<NL, NH>(RcpMant<NH>::run(narrow<NH, NL>(man)));
+    const Mw<NL> t = sub(from_u32<NL>(1), mul(man, r0));
+    return add(r0, mul(r0, t));
+  }
+};
+template <> struct RcpMant<3>
+{
+  static MW_HD Mw<3> run(const Mw<3> &man)
+  {
+    Mw<3> r = from_double<3>(1.0 / to_double(man));
+    const Mw<3> one = from_u32<3>(1);
+#pragma unroll
+    for(int it = 0; it < 2; ++it)
+      r = add(r, mul(r, sub(one, mul(man, r))));
+    return r;
+  }
+};
+template <> struct RcpMant<2>
+{
+  static MW_HD Mw<2> run(const Mw<2> &man)
+  {
+    Mw<2> r = from_double<2>(1.0 / to_double(man));
+    return add(r, mul(r, sub(from_u32<2>(1), mul(man, r))));
+  }
+};
+template <> struct RcpMant<1>
+{
+  static MW_HD Mw<1> run(const Mw<1> &man) { return from_double<1>(1.0 / to_double(man)); }
+};
 
 template <int NL> MW_HD Mw<NL> rcp(const Mw<NL> &a)
 {
   // caller guarantees a != 0
   Mw<NL> man = a;
   man.e = 0;
-  man.neg = 0; // in [0.5,1)
-  Mw<NL> r = from_double<NL>(1.0 / to_double(man));
-  const Mw<NL> one = from_u32<NL>(1);
-#pragma unroll 1
-  for(int it = 0; it < newton_iters<NL>(); ++it)
-    {
-      // r += r*(1 - man*r)
-      const Mw<NL> t = sub(one, mul(man, r));
-      r = add(r, mul(r, t));
-    }
+  man.neg = 0;
+  Mw<NL> r = RcpMant<NL>::run(man);
   r.e -= a.e;
   r.neg = a.neg;
   return r;
@@ -454,31 +498,61 @@ template <int NL> MW_HD Mw<NL> div(const Mw<NL> &a, const Mw<NL> &b)
   return add(q, mul(r, rem));
 }
 
+MW_HD double host_device_sqrt(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ::sqrt(x);
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+// 1/sqrt(man) for man in [0.5,2) (e in {0,1}, positive)
+template <int NL> struct RsqrtMant
+{
+  static MW_HD Mw<NL> run(const Mw<NL> &man)
+  {
+    constexpr int NH = NL / 2 + 1;
+    const Mw<NL> r0 = widen<NL, NH>(RsqrtMant<NH>::run(narrow<NH, NL>(man)));
+    // r = r0 + r0*(1 - man*r0^2)/2
+    const Mw<NL> t = sub(from_u32<NL>(1), mul(man, mul(r0, r0)));
+    return add(r0, mul_2exp(mul(r0, t), -1));
+  }
+};
+template <> struct RsqrtMant<3>
+{
+  static MW_HD Mw<3> run(const Mw<3> &man)
+  {
+    Mw<3> r = from_double<3>(1.0 / host_device_sqrt(to_double(man)));
+    const Mw<3> one = from_u32<3>(1);
+#pragma unroll
+    for(int it = 0; it < 2; ++it)
+      r = add(r, mul_2exp(mul(r, sub(one, mul(man, mul(r, r)))), -1));
+    return r;
+  }
+};
+template <> struct RsqrtMant<2>
+{
+  static MW_HD Mw<2> run(const Mw<2> &man)
+  {
+    Mw<2> r = from_double<2>(1.0 / host_device_sqrt(to_double(man)));
+    return add(r, mul_2exp(mul(r, sub(from_u32<2>(1), mul(man, mul(r, r)))), -1));
+  }
+};
+template <> struct RsqrtMant<1>
+{
+  static MW_HD Mw<1> run(const Mw<1> &man) { return from_double<1>(1.0 / host_device_sqrt(to_double(man))); }
+};
+
 // 1/sqrt(a), a > 0
 template <int NL> MW_HD Mw<NL> rsqrt(const Mw<NL> &a)
 {
   Mw<NL> man = a;
   int32_t e = a.e;
-  // make exponent even: man in [0.5,2)
-  const int odd = e & 1;
+  const int odd = e & 1; // make the exponent even: man in [0.5,2)
   man.e = odd;
   man.neg = 0;
   e -= odd;
-  double seed = to_double(man);
-#if defined(__HIP_DEVICE_COMPILE__)
-  seed = 1.0 / ::sqrt(seed);
-#else
-  seed = 1.0 / __builtin_sqrt(seed);
-#endif
-  Mw<NL> r = from_double<NL>(seed);
-  const Mw<NL> three = from_u32<NL>(3);
-#pragma unroll 1
-  for(int it = 0; it < newton_iters<NL>(); ++it)
-    {
-      // r = r*(3 - man*r^2)/2
-      const Mw<NL> t = sub(three, mul(man, mul(r, r)));
-      r = mul_2exp(mul(r, t), -1);
-    }
+  Mw<NL> r = RsqrtMant<NL>::run(man);
   r.e -= e / 2;
   return r;
 }

@@ -106,6 +106,7 @@ public:
   virtual void set_param(const std::string &name, const char *value) = 0;
   virtual void set_flags(long max_iterations, bool fpf, bool fdf, bool dpfj, bool ddfj) = 0;
   virtual void set_block(int j, const char *be, const char *bo, const char *B, const char *c) = 0;
+  virtual void set_block_f64(int j, const char *be, const char *bo, const double *B, const double *c) = 0;
   virtual void set_objective(const char *b, const char *constant) = 0;
   virtual void init_state() = 0;
   virtual bool iterate() = 0;
@@ -179,7 +180,7 @@ template <int NL> class Solver : public SolverBase
   // ---- device arrays ---------------------------------------------------------
   DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
   DevArray bases_, E_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
-  DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_;
+  DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_;
   DevBuf<unsigned long long> acc64_;
@@ -201,6 +202,9 @@ template <int NL> class Solver : public SolverBase
   long iteration_ = 0;
   int terminate_reason_ = NotTerminated;
   Collectives coll_;
+  hipEvent_t ev_syrk0_ = nullptr, ev_syrk1_ = nullptr;
+  double syrk_kernel_ms_ = 0;
+  long syrk_launches_ = 0;
   std::map<std::string, double> timers_ms_;
   std::vector<std::pair<std::string, double>> timer_order_;
 
@@ -221,11 +225,17 @@ public:
       throw SolverError(4, "sdpb_hip_create: need at least one block and N >= 1");
     owner_ = plan_block_owners(dims, num_points, N, world);
     HIP_CHECK(hipStreamCreate(&stream_));
+    HIP_CHECK(hipEventCreate(&ev_syrk0_));
+    HIP_CHECK(hipEventCreate(&ev_syrk1_));
     build_layout();
     set_default_params();
   }
   ~Solver() override
   {
+    if(ev_syrk0_)
+      (void)hipEventDestroy(ev_syrk0_);
+    if(ev_syrk1_)
+      (void)hipEventDestroy(ev_syrk1_);
     if(stream_)
       (void)hipStreamDestroy(stream_);
   }
@@ -303,6 +313,8 @@ private:
 
     // blocked Cholesky(Q) panels
     q_nb_ = N_ <= 96 ? N_ : 32;
+    if(const char *env = std::getenv("SDPB_HIP_Q_PANEL"))
+      q_nb_ = std::max(4, std::min(N_, std::atoi(env)));
     q_panels_ = (N_ + q_nb_ - 1) / q_nb_;
     std::vector<MatDesc> qd, qdv, qp, qt;
     for(int p = 0; p < q_panels_; ++p)
@@ -330,8 +342,8 @@ private:
     PT_.alloc(off_bt, NL);
     for(DevArray *a : {&c_, &x_, &dx_, &dres_, &invdS_})
       a->alloc(Ptot_, NL);
-    invdX_.alloc(off_vecn, NL);
-    invdY_.alloc(off_vecn, NL);
+    for(DevArray *a : {&invdX_, &invdY_, &eigD_, &eigE_})
+      a->alloc(off_vecn, NL);
     for(DevArray *a : {&b_, &y_, &dy_, &rp_, &norms_, &invnorms_, &invdQ_})
       a->alloc(N_, NL);
     Q_.alloc((size_t)N_ * N_, NL);
@@ -409,6 +421,11 @@ public:
         ss << (first ? "" : ", ") << "\"" << kv.first << "\": " << timers_ms_.at(kv.first);
         first = false;
       }
+    // dominant kernel: HIP-event time, launches, algorithmic bytes and limb MACs per launch
+    const double fx_bytes = (double)Ptot_ * N_ * (FX + 1) * 4.0, acc_bytes = (double)N_ * (N_ + 1) / 2 * ACCW * 4.0;
+    ss << (first ? "" : ", ") << "\"kernel.k_syrk_fx.ms\": " << syrk_kernel_ms_ << ", \"kernel.k_syrk_fx.launches\": " << syrk_launches_
+       << ", \"kernel.k_syrk_fx.algorithmic_bytes\": " << (fx_bytes + acc_bytes)
+       << ", \"kernel.k_syrk_fx.limb_macs\": " << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX;
     ss << "}";
     return ss.str();
   }
@@ -465,11 +482,38 @@ public:
   // Blocks owned by other ranks are ignored (every rank may be fed the whole SDP).
   void set_block(int j, const char *be, const char *bo, const char *B, const char *c) override
   {
+    const int l = set_block_bases(j, be, bo);
+    if(l < 0)
+      return;
+    const BlockDesc &bd = blk_[l];
+    // B[p][n] row-major is exactly B^T (N x P) column-major: element (n,p) at n + p*N
+    upload<NL>(BT_, h_bt_[l].off, parse_list(B, (size_t)bd.P * N_, "B"));
+    upload<NL>(c_, bd.voff, parse_list(c, bd.P, "c"));
+  }
+  // Same, with B (row-major P x N) and c given as doubles (exact conversion): bulk
+  // synthetic inputs whose entries are dyadic rationals.
+  void set_block_f64(int j, const char *be, const char *bo, const double *B, const double *c) override
+  {
+    const int l = set_block_bases(j, be, bo);
+    if(l < 0)
+      return;
+    const BlockDesc &bd = blk_[l];
+    std::vector<M> v((size_t)bd.P * N_);
+    for(size_t i = 0; i < v.size(); ++i)
+      v[i] = mw::from_double<NL>(B[i]);
+    upload<NL>(BT_, h_bt_[l].off, v);
+    v.resize(bd.P);
+    for(int i = 0; i < bd.P; ++i)
+      v[i] = mw::from_double<NL>(c[i]);
+    upload<NL>(c_, bd.voff, v);
+  }
+  int set_block_bases(int j, const char *be, const char *bo)
+  {
     if(j < 0 || j >= J_)
       throw SolverError(4, "set_block: block index out of range");
     const int l = local_index(j);
     if(l < 0)
-      return;
+      return -1;
     const BlockDesc &bd = blk_[l];
     const char *src[2] = {be, bo};
     for(int b = 0; b < 2; ++b)
@@ -481,20 +525,15 @@ public:
             cm[(size_t)k * rs + r] = v[(size_t)r * bd.K + k];
         upload<NL>(bases_, h_bases_[2 * l + b].off, cm);
       }
-    {
-      // B[p][n] row-major is exactly B^T (N x P) column-major: element (n,p) at n + p*N
-      std::vector<M> v = parse_list(B, (size_t)bd.P * N_, "B");
-      upload<NL>(BT_, h_bt_[l].off, v);
-    }
-    upload<NL>(c_, bd.voff, parse_list(c, bd.P, "c"));
     // bases_blocks (set_bases_blocks.cxx:3-22) for this block's two parities
     Batch bb = basesB(), ee = eB(E_);
     bb.d += 2 * l;
     ee.d += 2 * l;
     bb.count = ee.count = 2;
     const size_t mx = std::max((size_t)bd.n[0] * bd.m * bd.K, (size_t)bd.n[1] * bd.m * bd.K);
-    launch(k_build_bases_block<NL>, dim3(cdiv(mx, WG), 2), dim3(WG), stream_, bb, ee, d_blk_.p + l); // the kernel indexes blk[q>>1], q in {0,1}: relative to this block
+    launch(k_build_bases_block<NL>, dim3(cdiv(mx, WG), 2), dim3(WG), stream_, bb, ee, d_blk_.p + l);
     HIP_CHECK(hipStreamSynchronize(stream_));
+    return l;
   }
   void set_objective(const char *b, const char *constant) override
   {
@@ -841,8 +880,18 @@ private:
                invnorms_.cptr(), fx_.p, fx_stride_);
       const unsigned tiles = cdiv(N_, 16);
       if(cnt)
-        launch(k_syrk_fx<FX, SYRK_RB>, dim3(tiles * (tiles + 1) / 2), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_, (size_t)0,
-               Ptot_, N_, acc_.p, acc_stride_, 0);
+        {
+          // HIP events on the launch stream bracket the dominant kernel (bench.py roofline)
+          HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
+          launch(k_syrk_fx<FX, SYRK_RB>, dim3(tiles * (tiles + 1) / 2), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_,
+                 (size_t)0, Ptot_, N_, acc_.p, acc_stride_, 0);
+          HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
+          HIP_CHECK(hipEventSynchronize(ev_syrk1_));
+          float ms = 0;
+          HIP_CHECK(hipEventElapsedTime(&ms, ev_syrk0_, ev_syrk1_));
+          syrk_kernel_ms_ += ms;
+          syrk_launches_ += 1;
+        }
       else
         HIP_CHECK(hipMemsetAsync(acc_.p, 0, acc_.n * sizeof(uint32_t), stream_));
       if(world_ > 1)
@@ -900,38 +949,68 @@ private:
   // solve_schur_complement_equation.cxx:16-79
   void solve_schur_complement_equation()
   {
-    launch(k_vec_solve<NL, false>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
-    gemv_t_all<false>(PT_, dx_, &rp_, -1, dy_); // dy = p - sum_j P_j^T dx_j
-    launch(k_vec_solve<NL, false>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
-    launch(k_vec_solve<NL, true>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
-    launch(k_gemv_n_add<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, btB(PT_), dy_.cptr(), dx_.ptr(), d_blk_.p, N_);
-    launch(k_vec_solve<NL, true>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
+    {
+      Timer t(this, "searchDirection.solve.dx_Linv");
+      launch(k_vec_solve<NL, false>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
+    }
+    {
+      Timer t(this, "searchDirection.solve.dy_PTdx");
+      gemv_t_all<false>(PT_, dx_, &rp_, -1, dy_); // dy = p - sum_j P_j^T dx_j
+    }
+    {
+      Timer t(this, "searchDirection.solve.dy_Qinv");
+      launch(k_vec_solve<NL, false>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
+      launch(k_vec_solve<NL, true>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
+    }
+    {
+      Timer t(this, "searchDirection.solve.dx_Pdy");
+      launch(k_gemv_n_add<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, btB(PT_), dy_.cptr(), dx_.ptr(), d_blk_.p, N_);
+    }
+    {
+      Timer t(this, "searchDirection.solve.dx_LTinv");
+      launch(k_vec_solve<NL, true>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
+    }
   }
 
   // compute_search_direction.cxx:44-90
   void compute_search_direction(const M &beta, bool corrector)
   {
-    // R = beta mu I - XY (- dX dY)
-    copy(mXY_, R_);
-    if(corrector)
-      gemm_psd(false, dX_, dY_, R_, true, true);
-    upload_scalar(S_BETAMU, mw::mul(beta, mu_));
-    add_diagonal(R_, S_BETAMU);
-    // Z = Symmetrize(X^{-1} (PrimalResidues Y - R))
-    gemm_psd(false, PR_, Y_, Z_, false, false);
-    sub_inplace(Z_, R_);
-    cholesky_solve_X(Z_);
-    symmetrize(Z_, false);
-    // dx = -d - Tr(A_p Z) ; dy = p
-    launch(k_schur_rhs<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, basesB(), psd(Z_), dres_.cptr(), dx_.ptr(), d_blk_.p);
+    {
+      // R = beta mu I - XY (- dX dY)
+      Timer t(this, "searchDirection.R");
+      copy(mXY_, R_);
+      if(corrector)
+        gemm_psd(false, dX_, dY_, R_, true, true);
+      upload_scalar(S_BETAMU, mw::mul(beta, mu_));
+      add_diagonal(R_, S_BETAMU);
+    }
+    {
+      // Z = Symmetrize(X^{-1} (PrimalResidues Y - R))
+      Timer t(this, "searchDirection.Z");
+      gemm_psd(false, PR_, Y_, Z_, false, false);
+      sub_inplace(Z_, R_);
+      cholesky_solve_X(Z_);
+      symmetrize(Z_, false);
+    }
+    {
+      // dx = -d - Tr(A_p Z) ; dy = p
+      Timer t(this, "searchDirection.schur_RHS");
+      launch(k_schur_rhs<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, basesB(), psd(Z_), dres_.cptr(), dx_.ptr(), d_blk_.p);
+    }
     solve_schur_complement_equation();
-    // dX = PrimalResidues + sum_p A_p dx[p]
-    constraint_matrix_weighted_sum(dx_, dX_, PR_, +1);
-    // dY = Symmetrize(X^{-1} (R - dX Y))
-    gemm_psd(false, dX_, Y_, dY_, false, false);
-    sub_inplace(dY_, R_);
-    cholesky_solve_X(dY_);
-    symmetrize(dY_, true);
+    {
+      // dX = PrimalResidues + sum_p A_p dx[p]
+      Timer t(this, "searchDirection.dX");
+      constraint_matrix_weighted_sum(dx_, dX_, PR_, +1);
+    }
+    {
+      // dY = Symmetrize(X^{-1} (R - dX Y))
+      Timer t(this, "searchDirection.dY");
+      gemm_psd(false, dX_, Y_, dY_, false, false);
+      sub_inplace(dY_, R_);
+      cholesky_solve_X(dY_);
+      symmetrize(dY_, true);
+    }
   }
   void sub_inplace(DevArray &A, const DevArray &B)
   {
@@ -963,7 +1042,7 @@ private:
     copy(dM, W_);
     launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
     launch(k_trsm_lln<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
-    launch(k_jacobi_min_eig<NL>, dim3(2 * Jl_), dim3(WG), stream_, psd(W_), lam_.ptr(), 100);
+    launch(k_min_eig<NL>, dim3(2 * Jl_), dim3(EIG_T), stream_, psd(W_), vecn(eigD_), vecn(eigE_), lam_.ptr());
     mw::CPtr lp = lam_.cptr();
     M lambda = reduce<RED_MIN>((size_t)2 * Jl_, [=] __device__(size_t i) { return mw::load<NL>(lp, i); });
     if(Jl_ == 0)
@@ -1370,11 +1449,11 @@ public:
 };
 
 // one factory per compiled limb count (solver_nl.hip is built once per SDPB_NL)
-SolverBase *make_solver_6(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-SolverBase *make_solver_10(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-SolverBase *make_solver_16(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-SolverBase *make_solver_18(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-SolverBase *make_solver_24(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-SolverBase *make_solver_26(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-SolverBase *make_solver_34(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_6(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_10(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_16(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_18(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_24(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_26(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_34(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
 } // namespace sdpb

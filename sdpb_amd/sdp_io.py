@@ -50,10 +50,11 @@ class SDP:
     constant: str
     normalization: Optional[List[str]] = None
     path: str = ""
+    shape: Optional[tuple] = None  # (dims, num_points) when blocks are supplied lazily
 
     @property
     def J(self) -> int:
-        return len(self.blocks)
+        return len(self.shape[0]) if self.shape else len(self.blocks)
 
     @property
     def N(self) -> int:
@@ -61,15 +62,15 @@ class SDP:
 
     @property
     def dims(self):
-        return [blk.dim for blk in self.blocks]
+        return list(self.shape[0]) if self.shape else [blk.dim for blk in self.blocks]
 
     @property
     def num_points(self):
-        return [blk.num_points for blk in self.blocks]
+        return list(self.shape[1]) if self.shape else [blk.num_points for blk in self.blocks]
 
     @property
     def P_total(self) -> int:
-        return sum(blk.schur_size for blk in self.blocks)
+        return sum(K * m * (m + 1) // 2 for m, K in zip(self.dims, self.num_points))
 
 
 def _flat(rows) -> str:

@@ -68,6 +68,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_set_param.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
     L.sdpb_hip_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 4
     L.sdpb_hip_set_block.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_char_p] * 4
+    L.sdpb_hip_set_block_f64.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
+                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.sdpb_hip_set_objective.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
     L.sdpb_hip_init_state.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_iterate.argtypes = [ctypes.c_void_p, c_int_p]
@@ -108,7 +110,9 @@ def plan_blocks(dims: List[int], num_points: List[int], N: int, world_size: int,
 class SDPSolver:
     def __init__(self, sdp: SDP, precision: int, params: Optional[dict] = None, device: int = -1,
                  rank: int = 0, world_size: int = 1, lib_path: Optional[str] = None,
-                 upload_all_blocks: bool = True):
+                 upload_all_blocks: bool = True, block_source: Optional[Callable] = None):
+        """block_source(j) -> (bases_even_rows, bases_odd_rows, B float64 [P,N], c float64 [P]) supplies
+        blocks lazily as arrays (bulk synthetic inputs); otherwise sdp.blocks[j] holds decimal strings."""
         self.L = load_library(lib_path)
         self.sdp = sdp
         self.precision = precision
@@ -123,9 +127,20 @@ class SDPSolver:
         self.h = h
         self._cb_keepalive = None
         self.set_params(params or {})
-        for j, blk in enumerate(sdp.blocks):
-            if upload_all_blocks or self.block_owner(j) == rank:
-                self._chk(self.L.sdpb_hip_set_block(self.h, j, *block_text(blk)))
+        for j in range(J):
+            if not (upload_all_blocks or self.block_owner(j) == rank):
+                continue
+            if block_source is not None:
+                import numpy as np
+                be, bo, B, c = block_source(j)
+                B = np.ascontiguousarray(B, dtype=np.float64)
+                c = np.ascontiguousarray(c, dtype=np.float64)
+                dp = ctypes.POINTER(ctypes.c_double)
+                self._chk(self.L.sdpb_hip_set_block_f64(
+                    self.h, j, "\n".join(" ".join(r) for r in be).encode(),
+                    "\n".join(" ".join(r) for r in bo).encode(), B.ctypes.data_as(dp), c.ctypes.data_as(dp)))
+            else:
+                self._chk(self.L.sdpb_hip_set_block(self.h, j, *block_text(sdp.blocks[j])))
         self._chk(self.L.sdpb_hip_set_objective(self.h, " ".join(sdp.b).encode(), sdp.constant.encode()))
         self._chk(self.L.sdpb_hip_init_state(self.h))
         self.iteration = 0

@@ -69,3 +69,23 @@ def compare_iteration(got: dict, want: dict, tol_bits: int = 99, skip_err_below_
         if l2 > -tol_bits:
             bad.append((k, l2))
     return bad, worst
+
+
+DEFAULT_PARAMS = {  # Solver_Parameters.cxx:10-157
+    "dualityGapThreshold": "1e-30", "primalErrorThreshold": "1e-30", "dualErrorThreshold": "1e-30",
+    "initialMatrixScalePrimal": "1e20", "initialMatrixScaleDual": "1e20",
+    "feasibleCenteringParameter": "0.1", "infeasibleCenteringParameter": "0.3",
+    "stepLengthReduction": "0.7", "maxComplementarity": "1e100", "minPrimalStep": "0", "minDualStep": "0"}
+FLAG_KEYS = {"maxIterations", "findPrimalFeasible", "findDualFeasible", "detectPrimalFeasibleJump",
+             "detectDualFeasibleJump"}
+
+
+def reference_params(params: dict, oracle) -> dict:
+    """The parameter VALUES the reference actually ran with: sdpb parses its options before
+    --precision is applied, i.e. at GMP's initial 64-bit precision (visible in the golden
+    traces: beta = 0.2999...98725e-58 in 1d/iterations.json).  Returns exact decimals."""
+    full = dict(DEFAULT_PARAMS)
+    full.update({k: v for k, v in params.items() if k not in FLAG_KEYS})
+    out = {k: oracle.parse_exact(v, 64) for k, v in full.items()}
+    out.update({k: v for k, v in params.items() if k in FLAG_KEYS})
+    return out

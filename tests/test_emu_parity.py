@@ -1,0 +1,48 @@
+"""Host logic + kernel index arithmetic of the product sources, exercised on the CPU
+emulation build (tests/emu) against the reference's golden traces.  Tolerance: the
+reference's own 2^-99 (tests/parity.py).  The real gfx950 library is checked by
+tests/test_gpu_parity.py."""
+import pytest
+
+from sdpb_amd.solver import SDPSolver
+from tests import libs, parity
+
+CASES = [("1d", 12), ("1d-constraints", 6), ("dfibo", None)]
+
+
+@pytest.mark.parametrize("name,limit", CASES)
+def test_emulated_library_matches_reference_golden(name, limit):
+    sdp, meta, iters, out = parity.load_case(name)
+    s = SDPSolver(sdp, meta["precision"], meta["params"], lib_path=libs.emu_lib())
+    n = len(iters) if limit is None else limit
+    for rec in iters[:n]:
+        assert not s.iterate(), (name, rec["iteration"], s.terminate_reason)
+        bad, _ = parity.compare_iteration(s.scalars(), rec)
+        assert not bad, f"{name} iteration {rec['iteration']}: {bad}"
+    if limit is None:
+        assert s.iterate()
+        assert s.terminate_reason == out["terminateReason"]
+        assert parity.log2_rel(s.scalar("primalObjective"), out["primalObjective"]) <= -99
+    s.close()
+
+
+def test_emulated_int_syrk_is_exact():
+    import random
+    from oracle.oracle import Oracle
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, 128, lib_path=libs.emu_lib())  # NL=6 -> FX=4: |v| < 2^128
+    o = Oracle(sdp, 128)
+    rng = random.Random(7)
+    rows, cols = 37, 21
+    vals = [rng.randrange(-(2 ** 128) + 1, 2 ** 128) for _ in range(rows * cols)]
+    vals[5] = 0
+    vals[11] = 2 ** 128 - 1
+    vals[12] = -(2 ** 128) + 1
+    got = s.op_int_syrk(rows, cols, vals)
+    want = o.int_syrk(rows, cols, vals)  # upper triangle, column-major
+    for j in range(cols):
+        for i in range(cols):
+            if i >= j:
+                assert got[i + j * cols] == want[j + i * cols], (i, j)
+            else:
+                assert got[i + j * cols] == 0

@@ -1,0 +1,119 @@
+"""Parity of the gfx950 library (through the C ABI) with the oracle and the reference's
+golden traces.  Run on the GPU box: python -m pytest tests -m gpu."""
+import random
+
+import mpmath
+import pytest
+
+from sdpb_amd.solver import SDPSolver
+from tests import libs, parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(sdp, precision, params=None):
+    return SDPSolver(sdp, precision, params or {}, lib_path=libs.product_lib())
+
+
+# ---- arithmetic: device ops vs GMP mpf (oracle), tolerance 2 ulp of the device mantissa
+@pytest.mark.parametrize("precision", [128, 256, 512, 768, 1024])
+def test_device_arithmetic_matches_mpf(precision):
+    from oracle.oracle import Oracle
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    # oracle computes at a much higher precision: exact reference values
+    o = Oracle(sdp, 4 * precision + 256)
+    bits = 32 * s.limbs
+    rng = random.Random(precision)
+    for _ in range(40):
+        a = mpmath.mpf(rng.uniform(-1, 1)) * mpmath.mpf(10) ** rng.randint(-40, 40)
+        b = mpmath.mpf(rng.uniform(-1, 1)) * mpmath.mpf(10) ** rng.randint(-40, 40)
+        sa, sb = mpmath.nstr(a, 40), mpmath.nstr(b, 40)
+        for op in ("add", "sub", "mul", "div", "sqrt"):
+            xa = sa.lstrip("-") if op == "sqrt" else sa
+            got, want = s.op_scalar(op, xa, sb), o.scalar_op(op, xa, sb)
+            assert parity.log2_rel(got, want) <= -(bits - 2), (op, sa, sb)
+    s.close()
+
+
+# ---- the dominant kernel: fixed-point syrk is bit exact (integers)
+@pytest.mark.parametrize("precision,rows,cols", [(128, 37, 21), (512, 300, 50), (512, 9, 1), (1024, 64, 33)])
+def test_int_syrk_bit_exact(precision, rows, cols):
+    from oracle.oracle import Oracle
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    o = Oracle(sdp, precision)
+    fxbits = 32 * (s.limbs - 2)
+    rng = random.Random(rows * cols)
+    vals = [rng.randrange(-(2 ** fxbits) + 1, 2 ** fxbits) for _ in range(rows * cols)]
+    vals[0] = 0
+    vals[-1] = 2 ** fxbits - 1
+    got = s.op_int_syrk(rows, cols, vals)
+    want = o.int_syrk(rows, cols, vals)
+    for j in range(cols):
+        for i in range(j, cols):
+            assert got[i + j * cols] == want[j + i * cols], (i, j)
+    s.close()
+
+
+# ---- whole iterations vs the reference's golden traces (reference tolerance 2^-99)
+GOLDEN = [("1d", None), ("1d-old-sampling", 40), ("1d-duplicate-poles", 40), ("1d-constraints", None),
+          ("dfibo", None), ("singlet_cT", 30), ("singlet_allowed_primal_jump", None),
+          ("singlet_allowed_dual_jump", None)]
+
+
+@pytest.mark.parametrize("name,limit", GOLDEN)
+def test_gpu_matches_reference_golden(name, limit):
+    from oracle.oracle import Oracle
+    sdp, meta, iters, out = parity.load_case(name)
+    o = Oracle(sdp, meta["precision"], meta["params"], param_prec=64)
+    s = _solver(sdp, meta["precision"], parity.reference_params(meta["params"], o))
+    n = len(iters) if limit is None else min(limit, len(iters))
+    worst = float("-inf")
+    for rec in iters[:n]:
+        assert not s.iterate(), (name, rec["iteration"], s.terminate_reason)
+        bad, w = parity.compare_iteration(s.scalars(), rec)
+        worst = max(worst, w)
+        assert not bad, f"{name} iteration {rec['iteration']}: {bad}"
+    print(f"{name}: {n} iterations, worst log2 relative difference to the reference trace {worst:.1f}")
+    if limit is None:
+        assert s.iterate(), f"{name}: did not terminate after {n} iterations"
+        assert s.terminate_reason == out["terminateReason"]
+        for key in ("primalObjective", "dualObjective"):
+            assert parity.log2_rel(s.scalar(key), out[key]) <= -99, key
+    s.close()
+
+
+# ---- vs the oracle at the headline precision on a synthetic SDP (SURVEY.md §8d gate:
+# first 10 iterations within 2^-(p/2))
+@pytest.mark.parametrize("cfg,scale,iters", [("C2", 1.0, 10), ("C3", 0.02, 10), ("C4", 0.01, 6)])
+def test_gpu_matches_oracle_on_synthetic(cfg, scale, iters):
+    from oracle.oracle import Oracle
+    from sdpb_amd.synthetic import config, make_sdp
+    c = config(cfg, scale)
+    sdp = make_sdp(c["dims"], c["num_points"], c["N"], c["precision"], c["seed"])
+    p = c["precision"]
+    s = _solver(sdp, p, parity.DEFAULT_PARAMS)
+    o = Oracle(sdp, p, parity.DEFAULT_PARAMS, param_prec=0)
+    for it in range(iters):
+        ts, to = s.iterate(), o.iterate()
+        assert ts == to
+        if ts:
+            break
+        got, want = s.scalars(), o.scalars()
+        bad, _ = parity.compare_iteration(got, want, tol_bits=p // 2)
+        assert not bad, f"{cfg} iteration {it + 1}: {bad}"
+    s.close()
+
+
+def test_errors_name_the_block_like_the_reference():
+    from sdpb_amd.solver import SDPBError
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = _solver(sdp, meta["precision"])
+    n = len(s.array("X", 0, 0))
+    s.set_array("X", ["-1"] + ["0"] * (n - 1), 0, 0)  # not positive definite
+    with pytest.raises(SDPBError) as e:
+        s.iterate()
+    assert e.value.code == 1
+    assert "Block_Diagonal_Matrix X, block index = 0, parity = 0" in str(e.value)
+    s.close()
