@@ -120,40 +120,35 @@ template <int NL> void upload(const DevArray &a, size_t first, const std::vector
 {
   if(h.empty())
     return;
-  std::vector<uint32_t> plane(h.size());
-  for(int k = 0; k <= NL; ++k)
+  const size_t cnt = h.size();
+  std::vector<uint32_t> planes(cnt * (NL + 1));
+  for(size_t i = 0; i < cnt; ++i)
     {
-      for(size_t i = 0; i < h.size(); ++i)
-        {
-          const mw::Mw<NL> &v = h[i];
-          const bool z = v.e == mw::EZERO;
-          plane[i] = k == 0 ? (z ? 0u : ((v.neg << 31) | (uint32_t)(v.e + (int32_t)mw::EBIAS))) : (z ? 0u : v.m[k - 1]);
-        }
-      HIP_CHECK(hipMemcpy(a.base + (size_t)k * a.n + first, plane.data(), plane.size() * sizeof(uint32_t),
-                          hipMemcpyHostToDevice));
+      const mw::Mw<NL> &v = h[i];
+      const bool z = v.e == mw::EZERO;
+      planes[i] = z ? 0u : ((v.neg << 31) | (uint32_t)(v.e + (int32_t)mw::EBIAS));
+      for(int k = 0; k < NL; ++k)
+        planes[(size_t)(k + 1) * cnt + i] = z ? 0u : v.m[k];
     }
+  // one strided copy for all NL+1 planes
+  HIP_CHECK(hipMemcpy2D(a.base + first, a.n * sizeof(uint32_t), planes.data(), cnt * sizeof(uint32_t), cnt * sizeof(uint32_t),
+                        NL + 1, hipMemcpyHostToDevice));
 }
 template <int NL> std::vector<mw::Mw<NL>> download(const DevArray &a, size_t first, size_t count)
 {
   std::vector<mw::Mw<NL>> h(count);
   if(!count)
     return h;
-  std::vector<uint32_t> plane(count);
-  for(int k = 0; k <= NL; ++k)
+  std::vector<uint32_t> planes(count * (NL + 1));
+  HIP_CHECK(hipMemcpy2D(planes.data(), count * sizeof(uint32_t), a.base + first, a.n * sizeof(uint32_t), count * sizeof(uint32_t),
+                        NL + 1, hipMemcpyDeviceToHost));
+  for(size_t i = 0; i < count; ++i)
     {
-      HIP_CHECK(hipMemcpy(plane.data(), a.base + (size_t)k * a.n + first, count * sizeof(uint32_t),
-                          hipMemcpyDeviceToHost));
-      for(size_t i = 0; i < count; ++i)
-        {
-          if(k == 0)
-            {
-              const uint32_t hd = plane[i];
-              h[i].neg = hd >> 31;
-              h[i].e = hd ? (int32_t)((hd & 0x7fffffffu) - mw::EBIAS) : mw::EZERO;
-            }
-          else
-            h[i].m[k - 1] = plane[i];
-        }
+      const uint32_t hd = planes[i];
+      h[i].neg = hd >> 31;
+      h[i].e = hd ? (int32_t)((hd & 0x7fffffffu) - mw::EBIAS) : mw::EZERO;
+      for(int k = 0; k < NL; ++k)
+        h[i].m[k] = planes[(size_t)(k + 1) * count + i];
     }
   return h;
 }

@@ -160,44 +160,11 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_lower(Batch A, Ba
 }
 
 // ---------------------------------------------------------------------------
-// Triangular solves with many independent right-hand sides: one lane per RHS.
-// L lower, invd = 1/diag(L).   grid = (ceil(max_vectors/WG), batch)
+// Triangular solves with many independent right-hand sides: one lane per RHS ROW, so
+// that consecutive lanes read consecutive addresses (coalesced).  Column-wise solves of
+// the reference (El::Trsm LEFT: compute_A_X_inv.cxx:21, cholesky_solve.cxx:9) are run on
+// the transposed operand.  L lower, invd = 1/diag(L).  grid = (ceil(rows/WG), batch)
 // ---------------------------------------------------------------------------
-// X := L^{-1} X   (El::Trsm LEFT,LOWER,NORMAL; compute_A_X_inv.cxx:21,
-// cholesky_solve.cxx:9, lower_triangular_inverse_congruence.cxx:12)
-template <int NL> __global__ void __launch_bounds__(WG) k_trsm_lln(Batch L, Batch invd, Batch X)
-{
-  const int q = blockIdx.y;
-  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
-  const int c = blockIdx.x * WG + threadIdx.x;
-  if(c >= dx.cols)
-    return;
-  const int n = dl.rows;
-  for(int i = 0; i < n; ++i)
-    {
-      Mw<NL> acc = mat_ld<NL>(X, dx, i, c);
-      for(int k = 0; k < i; ++k)
-        acc = mw::fms(mat_ld<NL>(L, dl, i, k), mat_ld<NL>(X, dx, k, c), acc);
-      mat_st<NL>(X, dx, i, c, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + i)));
-    }
-}
-// X := L^{-T} X   (El::Trsm LEFT,LOWER,TRANSPOSE; cholesky_solve.cxx:9)
-template <int NL> __global__ void __launch_bounds__(WG) k_trsm_llt(Batch L, Batch invd, Batch X)
-{
-  const int q = blockIdx.y;
-  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
-  const int c = blockIdx.x * WG + threadIdx.x;
-  if(c >= dx.cols)
-    return;
-  const int n = dl.rows;
-  for(int i = n - 1; i >= 0; --i)
-    {
-      Mw<NL> acc = mat_ld<NL>(X, dx, i, c);
-      for(int k = i + 1; k < n; ++k)
-        acc = mw::fms(mat_ld<NL>(L, dl, k, i), mat_ld<NL>(X, dx, k, c), acc);
-      mat_st<NL>(X, dx, i, c, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + i)));
-    }
-}
 // X := X L^{-T}   (El::Trsm RIGHT,LOWER,TRANSPOSE; lower_triangular_inverse_
 // congruence.cxx:8).  With B stored transposed (N x P_j) this is also
 // schur_off_diagonal = L^{-1} B (compute_Q.cxx:48): P^T = B^T L^{-T}; one lane per
@@ -215,6 +182,25 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt(Batch L, Batc
       Mw<NL> acc = mat_ld<NL>(X, dx, r, j);
       for(int k = 0; k < j; ++k)
         acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, j, k), acc);
+      mat_st<NL>(X, dx, r, j, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + j)));
+    }
+}
+
+// X := X L^{-1}: the second half of cholesky_solve (cholesky_solve.cxx:9) applied to the
+// transposed right-hand side, (L^{-T} W)^T = W^T L^{-1}; one lane per row, coalesced.
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rln(Batch L, Batch invd, Batch X)
+{
+  const int q = blockIdx.y;
+  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
+  const int r = blockIdx.x * WG + threadIdx.x;
+  if(r >= dx.rows)
+    return;
+  const int n = dl.rows;
+  for(int j = n - 1; j >= 0; --j)
+    {
+      Mw<NL> acc = mat_ld<NL>(X, dx, r, j);
+      for(int k = j + 1; k < n; ++k)
+        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k, j), acc);
       mat_st<NL>(X, dx, r, j, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + j)));
     }
 }
@@ -254,17 +240,20 @@ template <int NL, bool TRANS> __global__ void __launch_bounds__(WG) k_vec_solve(
 
 // ---------------------------------------------------------------------------
 // Batched GEMM, one lane per output element, 16x16 output tile per workgroup.
-//   C = (+/-) op(A) B (+ C),   op = transpose if TA
+//   C = (+/-) op(A) op(B) (+ C),   op = transpose if TA / TB
 // sym: only tiles on/below the diagonal are computed and mirrored (El::Syrk LOWER +
 // MakeSymmetric, compute_A_X_inv.cxx:28-29; compute_A_Y.cxx:35,45).
 // Replaces El::Gemm at compute_A_Y.cxx:32,35, scale_multiply_add.cxx:10.
 // ---------------------------------------------------------------------------
-template <int NL, bool TA>
-__global__ void __launch_bounds__(WG) k_gemm(Batch A, Batch B, Batch C, int alpha_neg, int beta_one, int sym)
+// Extras: TB multiplies by B^T; trans_out stores C^T (so that the triangular solves
+// that follow run on rows with coalesced loads); has_sub fuses "- Sub(i,j)".
+template <int NL, bool TA, bool TB>
+__global__ void __launch_bounds__(WG)
+  k_gemm(Batch A, Batch B, Batch C, int alpha_neg, int beta_one, int sym, Batch Sub, int has_sub, int trans_out)
 {
   const int q = blockIdx.y;
   const MatDesc da = A.d[q], db = B.d[q], dc = C.d[q];
-  const int M = dc.rows, Nn = dc.cols, K = TA ? da.rows : da.cols;
+  const int M = trans_out ? dc.cols : dc.rows, Nn = trans_out ? dc.rows : dc.cols, K = TA ? da.rows : da.cols;
   const int tiles_i = (M + 15) / 16, tiles_j = (Nn + 15) / 16;
   const int tile = blockIdx.x;
   if(tile >= tiles_i * tiles_j)
@@ -279,15 +268,35 @@ __global__ void __launch_bounds__(WG) k_gemm(Batch A, Batch B, Batch C, int alph
   for(int k = 0; k < K; ++k)
     {
       const Mw<NL> a = TA ? mat_ld<NL>(A, da, k, i) : mat_ld<NL>(A, da, i, k);
-      acc = mw::fma(a, mat_ld<NL>(B, db, k, j), acc);
+      const Mw<NL> b = TB ? mat_ld<NL>(B, db, j, k) : mat_ld<NL>(B, db, k, j);
+      acc = mw::fma(a, b, acc);
     }
   if(alpha_neg)
     acc = mw::neg(acc);
+  if(has_sub)
+    acc = mw::sub(acc, mat_ld<NL>(Sub, Sub.d[q], i, j));
+  const int oi = trans_out ? j : i, oj = trans_out ? i : j;
   if(beta_one)
-    acc = mw::add(acc, mat_ld<NL>(C, dc, i, j));
-  mat_st<NL>(C, dc, i, j, acc);
+    acc = mw::add(acc, mat_ld<NL>(C, dc, oi, oj));
+  mat_st<NL>(C, dc, oi, oj, acc);
   if(sym && i != j)
-    mat_st<NL>(C, dc, j, i, acc);
+    mat_st<NL>(C, dc, oj, oi, acc);
+}
+
+// in-place transpose of square matrices
+template <int NL> __global__ void __launch_bounds__(WG) k_transpose(Batch A)
+{
+  const int q = blockIdx.y;
+  const MatDesc d = A.d[q];
+  const int idx = blockIdx.x * WG + threadIdx.x;
+  if(idx >= d.rows * d.rows)
+    return;
+  const int i = idx % d.rows, j = idx / d.rows;
+  if(i <= j)
+    return;
+  const Mw<NL> x = mat_ld<NL>(A, d, i, j), y = mat_ld<NL>(A, d, j, i);
+  mat_st<NL>(A, d, i, j, y);
+  mat_st<NL>(A, d, j, i, x);
 }
 
 // A = (A + A^T)/2, optionally negated (Block_Diagonal_Matrix::symmetrize, :95-109)
@@ -334,6 +343,141 @@ template <int NL> __global__ void __launch_bounds__(WG) k_syrk_down_lower(Batch 
 }
 
 // ---------------------------------------------------------------------------
+// Blocked Cholesky(Q) / Q-solve helpers.  The sequential part of a triangular
+// operation costs one dependent multi-word multiply-add (~1.5 us) per step, so the
+// dense N x N factor is processed in panels of nb columns: the nb x nb diagonal
+// factor is inverted once (cooperatively), after which panel solves and the four
+// Q^{-1} applications per iteration are short dot products spread over the chip.
+// ---------------------------------------------------------------------------
+// Linv = L^{-1} for a batch of small lower-triangular matrices; one workgroup per
+// matrix, the threads of a workgroup are split into n column teams.
+template <int NL> __global__ void __launch_bounds__(WG) k_tri_inverse(Batch L, Batch invd, Batch Linv)
+{
+  const int q = blockIdx.x;
+  const MatDesc dl = L.d[q], dv = invd.d[q], di = Linv.d[q];
+  const int n = dl.rows, t = threadIdx.x;
+  if(n <= 0)
+    return;
+  const int G = WG / n > 0 ? WG / n : 1; // threads per column team
+  // columns handled by this thread: c = t / G (+ multiples of WG/G when n > WG)
+  const int teams = WG / G;
+  for(int idx = t; idx < n * n; idx += WG)
+    {
+      const int r = idx % n, c = idx / n;
+      mat_st<NL>(Linv, di, r, c, r == c ? mw::from_u32<NL>(1) : mw::zero<NL>());
+    }
+  __syncthreads();
+  const int g = t % G;
+  for(int k = 0; k < n; ++k)
+    {
+      const Mw<NL> ik = mw::load<NL>(invd.p, (size_t)dv.off + k);
+      for(int c = t / G; c <= k; c += teams)
+        if(g == 0)
+          mat_st<NL>(Linv, di, k, c, mw::mul(mat_ld<NL>(Linv, di, k, c), ik));
+      __syncthreads();
+      for(int c = t / G; c <= k; c += teams)
+        {
+          const Mw<NL> xk = mat_ld<NL>(Linv, di, k, c);
+          if(mw::is_zero(xk))
+            continue;
+          for(int i = k + 1 + g; i < n; i += G)
+            mat_st<NL>(Linv, di, i, c, mw::fms(mat_ld<NL>(L, dl, i, k), xk, mat_ld<NL>(Linv, di, i, c)));
+        }
+      __syncthreads();
+    }
+}
+// Out(r,j) = sum_{k<=j} A(r,k) * Linv(j,k)   (= A * Linv^T, Linv lower): the panel solve
+// X L^T = A of the blocked Cholesky as a product with the inverted diagonal factor.
+template <int NL> __global__ void __launch_bounds__(WG) k_panel_mul_linvT(Batch A, Batch Linv, Batch Out)
+{
+  const MatDesc da = A.d[0], di = Linv.d[0], dout = Out.d[0];
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)da.rows * da.cols)
+    return;
+  const int r = (int)(idx % da.rows), j = (int)(idx / da.rows);
+  Mw<NL> acc = mw::zero<NL>();
+  for(int k = 0; k <= j; ++k)
+    acc = mw::fma(mat_ld<NL>(A, da, r, k), mat_ld<NL>(Linv, di, j, k), acc);
+  mat_st<NL>(Out, dout, r, j, acc);
+}
+template <int NL> __global__ void __launch_bounds__(WG) k_copy_mat(Batch Src, Batch Dst)
+{
+  const MatDesc ds = Src.d[0], dd = Dst.d[0];
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)ds.rows * ds.cols)
+    return;
+  const int r = (int)(idx % ds.rows), c = (int)(idx / ds.rows);
+  mat_st<NL>(Dst, dd, r, c, mat_ld<NL>(Src, ds, r, c));
+}
+// One panel step of the blocked substitution with the Cholesky factor of Q
+// (El::cholesky::SolveAfter, solve_schur_complement_equation.cxx:64):
+//   xp = Linv_pp * rhs[k0..k0+nb)            (TRANS: Linv_pp^T)
+//   out[k0..k0+nb) = xp                      (written by workgroup 0)
+//   forward : rhs[r] -= sum_k L(r, k0+k) xp[k]   for r >= k0+nb
+//   backward: rhs[r] -= sum_k L(k0+k, r) xp[k]   for r <  k0        (TRANS)
+// Every workgroup recomputes the small diagonal product (so one launch per panel
+// suffices) and owns QS_ROWS rows of the update; each dot product is split over
+// QS_SEG lanes and reduced through LDS, so the dependent chain per launch is
+// 2*(nb/QS_SEG + QS_SEG) multi-word operations instead of 2*nb.
+constexpr int QS_ROWS = 32, QS_SEG = 8; // QS_ROWS * QS_SEG == WG; nb <= QS_ROWS
+template <int NL, bool TRANS>
+__global__ void __launch_bounds__(WG) k_qsolve_panel(Batch Q, Batch Linv, mw::Ptr rhs, mw::Ptr out, int k0)
+{
+  const MatDesc dq = Q.d[0], di = Linv.d[0];
+  const int N = dq.rows, nb = di.rows, t = threadIdx.x;
+  const int i = t % QS_ROWS, seg = t / QS_ROWS;
+  const int kper = (nb + QS_SEG - 1) / QS_SEG;
+  __shared__ Mw<NL> sx[QS_ROWS], sxp[QS_ROWS], part[WG];
+  if(t < nb)
+    sx[t] = mw::load<NL>(rhs, (size_t)k0 + t);
+  __syncthreads();
+  Mw<NL> acc = mw::zero<NL>();
+  if(i < nb)
+    for(int k = seg * kper; k < (seg + 1) * kper && k < nb; ++k)
+      {
+        if(!TRANS && k <= i)
+          acc = mw::fma(mat_ld<NL>(Linv, di, i, k), sx[k], acc);
+        if(TRANS && k >= i)
+          acc = mw::fma(mat_ld<NL>(Linv, di, k, i), sx[k], acc);
+      }
+  part[t] = acc;
+  __syncthreads();
+  if(t < nb)
+    {
+      Mw<NL> s = part[t];
+      for(int g = 1; g < QS_SEG; ++g)
+        s = mw::add(s, part[g * QS_ROWS + t]);
+      sxp[t] = s;
+      if(blockIdx.x == 0)
+        mw::store<NL>(out, (size_t)k0 + t, s);
+    }
+  __syncthreads();
+  const int first = TRANS ? 0 : k0 + nb, count = TRANS ? k0 : N - k0 - nb;
+  const int ri = blockIdx.x * QS_ROWS + i;
+  acc = mw::zero<NL>();
+  if(ri < count)
+    {
+      const int r = first + ri;
+      for(int k = seg * kper; k < (seg + 1) * kper && k < nb; ++k)
+        {
+          const Mw<NL> l = TRANS ? mat_ld<NL>(Q, dq, k0 + k, r) : mat_ld<NL>(Q, dq, r, k0 + k);
+          acc = mw::fma(l, sxp[k], acc);
+        }
+    }
+  __syncthreads();
+  part[t] = acc;
+  __syncthreads();
+  if(seg == 0 && ri < count)
+    {
+      Mw<NL> s = part[t];
+      for(int g = 1; g < QS_SEG; ++g)
+        s = mw::add(s, part[g * QS_ROWS + t]);
+      const size_t r = (size_t)first + ri;
+      mw::store<NL>(rhs, r, mw::sub(mw::load<NL>(rhs, r), s));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Block-structure helpers shared by the SDP-specific kernels
 // ---------------------------------------------------------------------------
 struct BlockDesc // one SDP block j (local index)
@@ -354,11 +498,13 @@ MW_HD void decode_p(int p, int K, int &cb, int &rb, int &k)
   rb = t - cb * (cb + 1) / 2;
 }
 
-// bases_blocks[2j+b] = I_m (x) bilinear_bases[2j+b]   (set_bases_blocks.cxx:3-22)
-template <int NL> __global__ void __launch_bounds__(WG) k_build_bases_block(Batch bases, Batch E, const BlockDesc *blk)
+// bases_blocks[2j+b] = I_m (x) bilinear_bases[2j+b]   (set_bases_blocks.cxx:3-22); Et
+// receives the transpose (rows of E^T are the right-hand sides of the pairing solve).
+template <int NL>
+__global__ void __launch_bounds__(WG) k_build_bases_block(Batch bases, Batch E, Batch Et, const BlockDesc *blk)
 {
   const int q = blockIdx.y;
-  const MatDesc de = E.d[q], dbs = bases.d[q];
+  const MatDesc de = E.d[q], dbs = bases.d[q], det = Et.d[q];
   const int rs = blk[q >> 1].rows[q & 1], K = blk[q >> 1].K;
   const int idx = blockIdx.x * WG + threadIdx.x;
   if(idx >= de.rows * de.cols)
@@ -368,6 +514,7 @@ template <int NL> __global__ void __launch_bounds__(WG) k_build_bases_block(Batc
   if(row / rs == col / K)
     v = mat_ld<NL>(bases, dbs, row % rs, col % K);
   mat_st<NL>(E, de, row, col, v);
+  mat_st<NL>(Et, det, col, row, v);
 }
 
 // Schur complement assembly (compute_schur_complement.cxx:15-125): element-wise in
@@ -409,11 +556,10 @@ __global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Bat
     mat_st<NL>(S, ds, C, R, e);
 }
 
-// dual_residues[p] = c[p] - sum_b diag(A_Y tile)[k] - (B y)[p]
-// (compute_dual_residues_and_error.cxx:7-66).  BT is B^T (N x P), one lane per p.
+// dual_residues[p] = c[p] - sum_b diag(A_Y tile)[k]   (the -(B y)[p] term is added by
+// k_gemv_n; compute_dual_residues_and_error.cxx:7-66).  One lane per p.
 template <int NL>
-__global__ void __launch_bounds__(WG)
-  k_dual_residues(Batch AY, Batch BT, mw::CPtr c, mw::CPtr y, mw::Ptr d, const BlockDesc *blk, int N)
+__global__ void __launch_bounds__(WG) k_dual_residues(Batch AY, mw::CPtr c, mw::Ptr d, const BlockDesc *blk)
 {
   const int j = blockIdx.y;
   const BlockDesc bl = blk[j];
@@ -428,11 +574,7 @@ __global__ void __launch_bounds__(WG)
       const MatDesc dy = AY.d[2 * j + b];
       acc = mw::sub(acc, mat_ld<NL>(AY, dy, cb * bl.K + k, rb * bl.K + k));
     }
-  const MatDesc db = BT.d[j];
-  Mw<NL> by = mw::zero<NL>();
-  for(int n = 0; n < N; ++n)
-    by = mw::fma(mat_ld<NL>(BT, db, n, p), mw::load<NL>(y, n), by);
-  mw::store<NL>(d, (size_t)bl.voff + p, mw::sub(acc, by));
+  mw::store<NL>(d, (size_t)bl.voff + p, acc);
 }
 
 // result = sum_p a[p] A_p (+/- addend)   (constraint_matrix_weighted_sum.cxx:14-66)
@@ -535,20 +677,40 @@ __global__ void __launch_bounds__(WG) k_sum_partials(mw::CPtr part, int J, int N
     acc = mw::add(mw::load<NL>(base, n), acc);
   mw::store<NL>(out, n, acc);
 }
-// dx_j[p] += sum_n PT_j(n,p) dy[n]   (solve_schur_complement_equation.cxx:69-74)
+// out_j[p] += sign * sum_n MT_j(n,p) v[n]: dx += P dy (solve_schur_complement_equation.
+// cxx:69-74) and d -= B y (compute_dual_residues_and_error.cxx:52-54).  A workgroup
+// owns 4 values of p; 64 lanes stride over n (coalesced column reads) and meet in an
+// LDS tree, so the dependent chain is N/64 + 6 instead of N.
 template <int NL>
-__global__ void __launch_bounds__(WG) k_gemv_n_add(Batch PT, mw::CPtr dy, mw::Ptr dx, const BlockDesc *blk, int N)
+__global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out, const BlockDesc *blk, int N, int sign)
 {
   const int j = blockIdx.y;
   const BlockDesc bl = blk[j];
-  const int p = blockIdx.x * WG + threadIdx.x;
-  if(p >= bl.P)
-    return;
-  const MatDesc dm = PT.d[j];
-  Mw<NL> acc = mw::load<NL>(dx, (size_t)bl.voff + p);
-  for(int n = 0; n < N; ++n)
-    acc = mw::fma(mat_ld<NL>(PT, dm, n, p), mw::load<NL>(dy, n), acc);
-  mw::store<NL>(dx, (size_t)bl.voff + p, acc);
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + sub;
+  __shared__ Mw<NL> sm[WG];
+  Mw<NL> acc = mw::zero<NL>();
+  if(p < bl.P)
+    {
+      const MatDesc dm = MT.d[j];
+      for(int n = lane; n < N; n += 64)
+        acc = mw::fma(mat_ld<NL>(MT, dm, n, p), mw::load<NL>(v, n), acc);
+    }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for(int s = 32; s > 0; s >>= 1)
+    {
+      if(lane < s)
+        sm[threadIdx.x] = mw::add(sm[threadIdx.x], sm[threadIdx.x + s]);
+      __syncthreads();
+    }
+  if(lane == 0 && p < bl.P)
+    {
+      Mw<NL> r = sm[threadIdx.x];
+      if(sign < 0)
+        r = mw::neg(r);
+      mw::store<NL>(out, (size_t)bl.voff + p, mw::add(mw::load<NL>(out, (size_t)bl.voff + p), r));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -783,14 +945,14 @@ __global__ void __launch_bounds__(WG)
 // Smallest eigenvalue of a batch of symmetric matrices (in place, lower triangle
 // referenced).  Replaces El::HermitianEig + El::Min at min_eigenvalue.cxx:8-33.
 // Like Elemental: Householder reduction to tridiagonal form (one wavefront per
-// matrix, reductions through LDS), then only the eigenvalue that is needed:
+// matrix, reductions through LDS; k_tridiag), then only the eigenvalue that is needed
+// (k_tridiag_min, one lane per matrix):
 // lambda_min of the tridiagonal matrix by an fp64 Sturm bisection (a safe starting
 // point below the spectrum) refined with Newton's method on det(T - lambda) in full
 // multi-word precision — monotone from below, quadratically convergent.
 // lam[q] = lambda_min (zero-size matrices write +huge so they never win the MIN).
 // ---------------------------------------------------------------------------
 constexpr int EIG_T = 64;      // one wavefront per matrix
-constexpr int EIG_MAX_N = 512; // fp64 staging of the tridiagonal matrix in LDS
 
 template <int NL> __device__ Mw<NL> eig_reduce_sum(const Mw<NL> &v)
 {
@@ -827,25 +989,17 @@ __device__ inline int sturm_count_f64(const double *a, const double *b2, int n, 
   return cnt;
 }
 
-template <int NL> __global__ void __launch_bounds__(EIG_T) k_min_eig(Batch A, Batch D, Batch E, mw::Ptr lam)
+// Stage 1: Householder tridiagonalisation (EISPACK tred1 organisation), one wavefront
+// per matrix.  D = diagonal, E[1..n) = off-diagonal of the tridiagonal matrix.
+template <int NL> __global__ void __launch_bounds__(EIG_T) k_tridiag(Batch A, Batch D, Batch E)
 {
   const int q = blockIdx.x;
   const MatDesc d = A.d[q];
   const size_t od = (size_t)D.d[q].off, oe = (size_t)E.d[q].off;
   const int n = d.rows, t = threadIdx.x;
-  if(n == 0 || n > EIG_MAX_N)
-    {
-      if(t == 0)
-        {
-          Mw<NL> big = mw::from_u32<NL>(1);
-          big.e = 1 << 28;
-          mw::store<NL>(lam, q, big);
-        }
-      return;
-    }
+  if(n == 0)
+    return;
   __shared__ Mw<NL> s_hinv;
-  __shared__ double s_a[EIG_MAX_N], s_b2[EIG_MAX_N];
-  // ---- Householder tridiagonalisation (EISPACK tred1 organisation) -------------
   for(int i = n - 1; i >= 1; --i)
     {
       const int l = i - 1;
@@ -912,70 +1066,86 @@ template <int NL> __global__ void __launch_bounds__(EIG_T) k_min_eig(Batch A, Ba
       __syncthreads();
     }
   __syncthreads();
-  // diagonal, squared off-diagonal, common binary scale for the fp64 image
-  __shared__ int s_emax;
-  if(t == 0)
-    s_emax = mw::EZERO;
-  __syncthreads();
   for(int i = t; i < n; i += EIG_T)
-    {
-      const Mw<NL> di = mat_ld<NL>(A, d, i, i);
-      mw::store<NL>(D.p, od + i, di);
-      int e = di.e;
-      if(i >= 1)
-        {
-          const Mw<NL> ei = mw::load<NL>(E.p, oe + i);
-          e = ei.e > e ? ei.e : e;
-        }
-      atomicMax(&s_emax, e);
-    }
-  __syncthreads();
-  const int emax = s_emax;
-  for(int i = t; i < n; i += EIG_T)
-    {
-      s_a[i] = mw::to_double(mw::mul_2exp(mw::load<NL>(D.p, od + i), -emax));
-      double b = 0.0;
-      if(i >= 1)
-        {
-          const Mw<NL> ei = mw::load<NL>(E.p, oe + i);
-          b = mw::to_double(mw::mul_2exp(ei, -emax));
-          mw::store<NL>(E.p, oe + i, mw::mul(ei, ei)); // E now holds offdiag^2
-        }
-      s_b2[i] = b * b;
-    }
-  __syncthreads();
-  if(t != 0)
+    mw::store<NL>(D.p, od + i, mat_ld<NL>(A, d, i, i));
+}
+
+// Stage 2: lambda_min of each tridiagonal matrix, one lane per matrix.  fa/fb2 are
+// fp64 work arrays laid out like D/E.  E is overwritten by its square.
+template <int NL>
+__global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double *fa, double *fb2, mw::Ptr lam)
+{
+  const int q = blockIdx.x * EIG_T + threadIdx.x;
+  if(q >= D.count)
     return;
+  const size_t od = (size_t)D.d[q].off, oe = (size_t)E.d[q].off;
+  const int n = D.d[q].rows;
+  if(n == 0)
+    {
+      Mw<NL> big = mw::from_u32<NL>(1);
+      big.e = 1 << 28;
+      mw::store<NL>(lam, q, big);
+      return;
+    }
   if(n == 1)
     {
       mw::store<NL>(lam, q, mw::load<NL>(D.p, od));
       return;
     }
-  // ---- fp64: Gershgorin bounds + bisection for the smallest eigenvalue -------------
+  double *a = fa + od, *b2 = fb2 + od;
+  // common binary scale for the fp64 image; E := E^2
+  int emax = mw::EZERO;
+  for(int i = 0; i < n; ++i)
+    {
+      const int e1 = mw::load<NL>(D.p, od + i).e;
+      emax = e1 > emax ? e1 : emax;
+      if(i >= 1)
+        {
+          const int e2 = mw::load<NL>(E.p, oe + i).e;
+          emax = e2 > emax ? e2 : emax;
+        }
+    }
+  if(emax == mw::EZERO)
+    {
+      mw::store<NL>(lam, q, mw::zero<NL>());
+      return;
+    }
+  for(int i = 0; i < n; ++i)
+    {
+      a[i] = mw::to_double(mw::mul_2exp(mw::load<NL>(D.p, od + i), -emax));
+      double b = 0.0;
+      if(i >= 1)
+        {
+          const Mw<NL> ei = mw::load<NL>(E.p, oe + i);
+          b = mw::to_double(mw::mul_2exp(ei, -emax));
+          mw::store<NL>(E.p, oe + i, mw::mul(ei, ei));
+        }
+      b2[i] = b * b;
+    }
+  // fp64: Gershgorin bounds + Sturm bisection for the smallest eigenvalue
   double lo = 1e300, hi = -1e300;
   for(int i = 0; i < n; ++i)
     {
-      const double r = (i >= 1 ? mw::host_device_sqrt(s_b2[i]) : 0.0) + (i + 1 < n ? mw::host_device_sqrt(s_b2[i + 1]) : 0.0);
-      lo = s_a[i] - r < lo ? s_a[i] - r : lo;
-      hi = s_a[i] + r > hi ? s_a[i] + r : hi;
+      const double r = (i >= 1 ? mw::host_device_sqrt(b2[i]) : 0.0) + (i + 1 < n ? mw::host_device_sqrt(b2[i + 1]) : 0.0);
+      lo = a[i] - r < lo ? a[i] - r : lo;
+      hi = a[i] + r > hi ? a[i] + r : hi;
     }
   const double span = (hi - lo) > 0 ? (hi - lo) : 1.0;
   double blo = lo - 1e-9 * span, bhi = hi + 1e-9 * span;
   for(int it = 0; it < 80; ++it)
     {
       const double mid = 0.5 * (blo + bhi);
-      if(sturm_count_f64(s_a, s_b2, n, mid) >= 1)
+      if(sturm_count_f64(a, b2, n, mid) >= 1)
         bhi = mid;
       else
         blo = mid;
     }
   // safely below lambda_min of the exact tridiagonal matrix
-  const double start = blo - 1e-10 * span - 1e-300;
-  Mw<NL> x = mw::mul_2exp(mw::from_double<NL>(start), emax);
-  // ---- multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i -----------
+  Mw<NL> x = mw::mul_2exp(mw::from_double<NL>(blo - 1e-10 * span - 1e-300), emax);
+  // multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i
   const Mw<NL> minus_one = mw::from_i32<NL>(-1);
   Mw<NL> prev = x;
-  for(int it = 0; it < 200; ++it)
+  for(int it = 0; it < 100; ++it)
     {
       Mw<NL> S = mw::zero<NL>(), inv = mw::zero<NL>(), tq = mw::zero<NL>();
       bool overshoot = false;
@@ -999,15 +1169,14 @@ template <int NL> __global__ void __launch_bounds__(EIG_T) k_min_eig(Batch A, Ba
         }
       if(overshoot)
         {
-          // cannot happen from below in exact arithmetic; retreat halfway
-          x = mw::mul_2exp(mw::add(x, prev), -1);
-          if(mw::cmp(x, prev) == 0)
-            {
-              Mw<NL> back = mw::abs(x);
-              back.e -= 32 * NL - 8;
-              x = mw::sub(x, back);
-              prev = x;
-            }
+          // Newton from below never crosses the root in exact arithmetic: a non-positive
+          // pivot after a successful step means x already sits within rounding noise of
+          // lambda_min.  Before any step it means the fp64 start was not below: back off.
+          if(it > 0 && mw::cmp(x, prev) != 0)
+            break;
+          const Mw<NL> back = mw::mul_2exp(mw::from_double<NL>(span * 1e-6 * (double)(1 << (it < 20 ? it : 20))), emax);
+          x = mw::sub(x, back);
+          prev = x;
           continue;
         }
       if(mw::is_zero(S))
@@ -1015,7 +1184,8 @@ template <int NL> __global__ void __launch_bounds__(EIG_T) k_min_eig(Batch A, Ba
       const Mw<NL> delta = mw::neg(mw::rcp(S));
       prev = x;
       x = mw::add(x, delta);
-      if(mw::is_zero(delta) || mw::is_zero(x) || delta.e < x.e - 24 * NL)
+      // quadratic convergence: a step below 2^-(16NL+8) |x| leaves an error ~ step^2
+      if(mw::is_zero(delta) || mw::is_zero(x) || delta.e < x.e - (16 * NL + 8))
         break;
     }
   mw::store<NL>(lam, q, x);

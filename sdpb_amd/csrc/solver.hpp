@@ -170,19 +170,23 @@ template <int NL> class Solver : public SolverBase
 
   // ---- descriptors -----------------------------------------------------------
   DevBuf<BlockDesc> d_blk_;
+  DevBuf<MatDesc> d_Et_;
   DevBuf<MatDesc> d_psd_, d_bases_, d_E_, d_pair_, d_schur_, d_bt_, d_vecP_, d_vecn_, d_Q_, d_vecQ_;
+  std::vector<MatDesc> h_Et_;
   std::vector<MatDesc> h_psd_, h_bases_, h_E_, h_pair_, h_schur_, h_bt_, h_vecP_, h_vecn_;
   // blocked Cholesky(Q): per panel descriptors
-  DevBuf<MatDesc> d_qdiag_, d_qdiagv_, d_qpanel_, d_qtrail_;
+  DevBuf<MatDesc> d_qdiag_, d_qdiagv_, d_qpanel_, d_qtrail_, d_qinv_, d_qtmp_;
   int q_nb_ = 0, q_panels_ = 0;
   int max_n_ = 0, max_q_ = 0, max_P_ = 0;
 
   // ---- device arrays ---------------------------------------------------------
   DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
-  DevArray bases_, E_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
+  DevArray bases_, E_, Et_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
+  DevArray Qinv_, Qtmp_, qtmpv_;
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_;
+  DevBuf<double> eigF_;
   DevBuf<unsigned long long> acc64_;
   DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
   size_t fx_stride_ = 0, acc_stride_ = 0;
@@ -278,6 +282,7 @@ private:
             h_vecn_.push_back(MatDesc{off_vecn, n, 1, n, K});
             h_bases_.push_back(MatDesc{off_bases, bd.rows[b], K, bd.rows[b], K});
             h_E_.push_back(MatDesc{off_E, n, q, n, K});
+            h_Et_.push_back(MatDesc{off_E, q, n, q, K});
             h_pair_.push_back(MatDesc{off_pair, q, q, q, K});
             off_psd += (size_t)n * n;
             off_vecn += n;
@@ -304,6 +309,7 @@ private:
     d_vecn_.upload(h_vecn_);
     d_bases_.upload(h_bases_);
     d_E_.upload(h_E_);
+    d_Et_.upload(h_Et_);
     d_pair_.upload(h_pair_);
     d_schur_.upload(h_schur_);
     d_bt_.upload(h_bt_);
@@ -312,11 +318,11 @@ private:
     d_vecQ_.upload(std::vector<MatDesc>{MatDesc{0, N_, 1, N_, 0}});
 
     // blocked Cholesky(Q) panels
-    q_nb_ = N_ <= 96 ? N_ : 32;
-    if(const char *env = std::getenv("SDPB_HIP_Q_PANEL"))
-      q_nb_ = std::max(4, std::min(N_, std::atoi(env)));
+    q_nb_ = N_ <= QS_ROWS ? N_ : QS_ROWS;
+    if(const char *env = std::getenv("SDPB_HIP_Q_PANEL")) // tests: force several (ragged) panels on small N
+      q_nb_ = std::max(4, std::min(std::min(N_, QS_ROWS), std::atoi(env)));
     q_panels_ = (N_ + q_nb_ - 1) / q_nb_;
-    std::vector<MatDesc> qd, qdv, qp, qt;
+    std::vector<MatDesc> qd, qdv, qp, qt, qi, qtm;
     for(int p = 0; p < q_panels_; ++p)
       {
         const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
@@ -324,16 +330,20 @@ private:
         qdv.push_back(MatDesc{(unsigned long long)k0, nb, 1, nb, 0});
         qp.push_back(MatDesc{(unsigned long long)(k0 + nb) + (unsigned long long)k0 * N_, rest, nb, N_, 0});
         qt.push_back(MatDesc{(unsigned long long)(k0 + nb) + (unsigned long long)(k0 + nb) * N_, rest, rest, N_, 0});
+        qi.push_back(MatDesc{(unsigned long long)p * q_nb_ * q_nb_, nb, nb, nb, 0});
+        qtm.push_back(MatDesc{0, rest, nb, rest > 0 ? rest : 1, 0});
       }
     d_qdiag_.upload(qd);
     d_qdiagv_.upload(qdv);
     d_qpanel_.upload(qp);
     d_qtrail_.upload(qt);
+    d_qinv_.upload(qi);
+    d_qtmp_.upload(qtm);
 
     for(DevArray *a : {&X_, &Y_, &Xc_, &Yc_, &dX_, &dY_, &PR_, &mXY_, &R_, &Z_, &W_})
       a->alloc(off_psd, NL);
     bases_.alloc(off_bases, NL);
-    for(DevArray *a : {&E_, &T_, &YQ_})
+    for(DevArray *a : {&E_, &Et_, &T_, &YQ_})
       a->alloc(off_E, NL);
     AX_.alloc(off_pair, NL);
     AY_.alloc(off_pair, NL);
@@ -347,6 +357,10 @@ private:
     for(DevArray *a : {&b_, &y_, &dy_, &rp_, &norms_, &invnorms_, &invdQ_})
       a->alloc(N_, NL);
     Q_.alloc((size_t)N_ * N_, NL);
+    eigF_.alloc(2 * (off_vecn + 1));
+    Qinv_.alloc((size_t)q_panels_ * q_nb_ * q_nb_, NL);
+    Qtmp_.alloc((size_t)N_ * q_nb_, NL);
+    qtmpv_.alloc(N_, NL);
     part_.alloc((size_t)std::max(Jl_, 1) * N_, NL);
     red_.alloc(1024, NL);
     red2_.alloc(4, NL);
@@ -383,6 +397,7 @@ private:
   Batch vecn(const DevArray &a) const { return Batch{a.ptr(), d_vecn_.p, 2 * Jl_}; }
   Batch basesB() const { return Batch{bases_.ptr(), d_bases_.p, 2 * Jl_}; }
   Batch eB(const DevArray &a) const { return Batch{a.ptr(), d_E_.p, 2 * Jl_}; }
+  Batch etB(const DevArray &a) const { return Batch{a.ptr(), d_Et_.p, 2 * Jl_}; }
   Batch pairB(const DevArray &a) const { return Batch{a.ptr(), d_pair_.p, 2 * Jl_}; }
   Batch schurB() const { return Batch{S_.ptr(), d_schur_.p, Jl_}; }
   Batch btB(const DevArray &a) const { return Batch{a.ptr(), d_bt_.p, Jl_}; }
@@ -526,12 +541,13 @@ public:
         upload<NL>(bases_, h_bases_[2 * l + b].off, cm);
       }
     // bases_blocks (set_bases_blocks.cxx:3-22) for this block's two parities
-    Batch bb = basesB(), ee = eB(E_);
+    Batch bb = basesB(), ee = eB(E_), et = etB(Et_);
     bb.d += 2 * l;
     ee.d += 2 * l;
-    bb.count = ee.count = 2;
+    et.d += 2 * l;
+    bb.count = ee.count = et.count = 2;
     const size_t mx = std::max((size_t)bd.n[0] * bd.m * bd.K, (size_t)bd.n[1] * bd.m * bd.K);
-    launch(k_build_bases_block<NL>, dim3(cdiv(mx, WG), 2), dim3(WG), stream_, bb, ee, d_blk_.p + l);
+    launch(k_build_bases_block<NL>, dim3(cdiv(mx, WG), 2), dim3(WG), stream_, bb, ee, et, d_blk_.p + l);
     HIP_CHECK(hipStreamSynchronize(stream_));
     return l;
   }
@@ -697,19 +713,21 @@ private:
     launch(k_chol_lower<NL>, dim3(2 * Jl_), dim3(WG), stream_, psd(L), vecn(invd), flags_.p);
     check_chol_flags(2 * Jl_, name, false);
   }
-  void gemm_psd(bool ta, const DevArray &A, const DevArray &B, DevArray &C, bool alpha_neg, bool beta_one)
+  // C = (+/-) A B (+ C) on the PSD-shaped batch; sub != nullptr fuses "- sub"; trans_out
+  // stores the transpose
+  void gemm_psd(const DevArray &A, const DevArray &B, DevArray &C, bool alpha_neg, bool beta_one, const DevArray *sub = nullptr,
+                bool trans_out = false)
   {
     const unsigned tiles = cdiv(max_n_, 16) * cdiv(max_n_, 16);
-    if(ta)
-      launch(k_gemm<NL, true>, dim3(tiles, 2 * Jl_), dim3(WG), stream_, psd(A), psd(B), psd(C), (int)alpha_neg, (int)beta_one, 0);
-    else
-      launch(k_gemm<NL, false>, dim3(tiles, 2 * Jl_), dim3(WG), stream_, psd(A), psd(B), psd(C), (int)alpha_neg, (int)beta_one, 0);
+    launch(k_gemm<NL, false, false>, dim3(tiles, 2 * Jl_), dim3(WG), stream_, psd(A), psd(B), psd(C), (int)alpha_neg, (int)beta_one, 0,
+           psd(sub ? *sub : C), sub ? 1 : 0, (int)trans_out);
   }
-  // cholesky_solve.cxx:4-13 : A := Xc^{-T} Xc^{-1} A
-  void cholesky_solve_X(DevArray &A)
+  // cholesky_solve.cxx:4-13 on a transposed operand: At := At Xc^{-T} Xc^{-1}, i.e.
+  // (Xc^{-T} Xc^{-1} A)^T; one lane per row, every load coalesced
+  void cholesky_solve_X_transposed(DevArray &At)
   {
-    launch(k_trsm_lln<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(A));
-    launch(k_trsm_llt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(A));
+    launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(At));
+    launch(k_trsm_rln<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(At));
   }
 
   // ==========================================================================
@@ -735,12 +753,14 @@ private:
     Timer t(this, "bilinear_pairings");
     const unsigned tiles_q = cdiv(max_q_, 16) * cdiv(max_q_, 16);
     // A_X_inv = (Xc^{-1} E)^T (Xc^{-1} E)      compute_A_X_inv.cxx:18-29
-    copy(E_, T_);
-    launch(k_trsm_lln<NL>, dim3(cdiv(max_q_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), eB(T_));
-    launch(k_gemm<NL, true>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, eB(T_), eB(T_), pairB(AX_), 0, 0, 1);
+    // computed on the transpose: Tt = E^T Xc^{-T} (row solves), A_X_inv = Tt Tt^T
+    copy(Et_, T_);
+    launch(k_trsm_rlt<NL>, dim3(cdiv(max_q_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), etB(T_));
+    launch(k_gemm<NL, false, true>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, etB(T_), etB(T_), pairB(AX_), 0, 0, 1, pairB(AX_), 0, 0);
     // A_Y = E^T (Y E)                           compute_A_Y.cxx:30-45
-    launch(k_gemm<NL, false>, dim3(cdiv(max_n_, 16) * cdiv(max_q_, 16), 2 * Jl_), dim3(WG), stream_, psd(Y_), eB(E_), eB(YQ_), 0, 0, 0);
-    launch(k_gemm<NL, true>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, eB(E_), eB(YQ_), pairB(AY_), 0, 0, 1);
+    launch(k_gemm<NL, false, false>, dim3(cdiv(max_n_, 16) * cdiv(max_q_, 16), 2 * Jl_), dim3(WG), stream_, psd(Y_), eB(E_), eB(YQ_), 0, 0,
+           0, eB(YQ_), 0, 0);
+    launch(k_gemm<NL, true, false>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, eB(E_), eB(YQ_), pairB(AY_), 0, 0, 1, pairB(AY_), 0, 0);
   }
 
   M max_abs(const DevArray &a, size_t count)
@@ -753,8 +773,8 @@ private:
   void compute_dual_residues_and_error()
   {
     Timer t(this, "computeDualResidues");
-    launch(k_dual_residues<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, pairB(AY_), btB(BT_), c_.cptr(), y_.cptr(),
-           dres_.ptr(), d_blk_.p, N_);
+    launch(k_dual_residues<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, pairB(AY_), c_.cptr(), dres_.ptr(), d_blk_.p);
+    launch(k_gemv_n<NL>, dim3(cdiv(max_P_, 4), Jl_), dim3(WG), stream_, btB(BT_), y_.cptr(), dres_.ptr(), d_blk_.p, N_, -1);
     dual_error_ = allreduce_scalar(max_abs(dres_, Ptot_), RED_MAX);
   }
   // constraint_matrix_weighted_sum.cxx:14-66 (+ the add/subtract that follows it)
@@ -927,13 +947,15 @@ private:
     int *qflags = flags_.p + 2 * std::max(Jl_, 1);
     for(int p = 0; p < q_panels_; ++p)
       {
-        Batch dg{Q_.ptr(), d_qdiag_.p + p, 1}, dv{invdQ_.ptr(), d_qdiagv_.p + p, 1};
+        Batch dg{Q_.ptr(), d_qdiag_.p + p, 1}, dv{invdQ_.ptr(), d_qdiagv_.p + p, 1}, iv{Qinv_.ptr(), d_qinv_.p + p, 1};
         launch(k_chol_lower<NL>, dim3(1), dim3(WG), stream_, dg, dv, qflags);
+        launch(k_tri_inverse<NL>, dim3(1), dim3(WG), stream_, dg, dv, iv);
         const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
         if(rest <= 0)
           continue;
-        Batch pn{Q_.ptr(), d_qpanel_.p + p, 1}, tr{Q_.ptr(), d_qtrail_.p + p, 1};
-        launch(k_trsm_rlt<NL>, dim3(cdiv(rest, WG), 1), dim3(WG), stream_, dg, dv, pn);
+        Batch pn{Q_.ptr(), d_qpanel_.p + p, 1}, tr{Q_.ptr(), d_qtrail_.p + p, 1}, tm{Qtmp_.ptr(), d_qtmp_.p + p, 1};
+        launch(k_panel_mul_linvT<NL>, dim3(cdiv((size_t)rest * nb, WG)), dim3(WG), stream_, pn, iv, tm);
+        launch(k_copy_mat<NL>, dim3(cdiv((size_t)rest * nb, WG)), dim3(WG), stream_, tm, pn);
         const unsigned tiles = cdiv(rest, 16);
         launch(k_syrk_down_lower<NL>, dim3(tiles * (tiles + 1) / 2, 1), dim3(WG), stream_, pn, tr);
       }
@@ -959,12 +981,25 @@ private:
     }
     {
       Timer t(this, "searchDirection.solve.dy_Qinv");
-      launch(k_vec_solve<NL, false>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
-      launch(k_vec_solve<NL, true>, dim3(1), dim3(WG), stream_, QB(), vecQB(invdQ_), vecQB(dy_));
+      // El::cholesky::SolveAfter with the blocked factor: forward (dy -> qtmpv_), then
+      // backward (qtmpv_ -> dy); one launch per panel
+      for(int p = 0; p < q_panels_; ++p)
+        {
+          const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
+          Batch iv{Qinv_.ptr(), d_qinv_.p + p, 1};
+          launch(k_qsolve_panel<NL, false>, dim3(std::max(1u, cdiv(rest, QS_ROWS))), dim3(WG), stream_, QB(), iv, dy_.ptr(), qtmpv_.ptr(),
+                 k0);
+        }
+      for(int p = q_panels_ - 1; p >= 0; --p)
+        {
+          const int k0 = p * q_nb_;
+          Batch iv{Qinv_.ptr(), d_qinv_.p + p, 1};
+          launch(k_qsolve_panel<NL, true>, dim3(std::max(1u, cdiv(k0, QS_ROWS))), dim3(WG), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(), k0);
+        }
     }
     {
       Timer t(this, "searchDirection.solve.dx_Pdy");
-      launch(k_gemv_n_add<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, btB(PT_), dy_.cptr(), dx_.ptr(), d_blk_.p, N_);
+      launch(k_gemv_n<NL>, dim3(cdiv(max_P_, 4), Jl_), dim3(WG), stream_, btB(PT_), dy_.cptr(), dx_.ptr(), d_blk_.p, N_, 1);
     }
     {
       Timer t(this, "searchDirection.solve.dx_LTinv");
@@ -980,16 +1015,15 @@ private:
       Timer t(this, "searchDirection.R");
       copy(mXY_, R_);
       if(corrector)
-        gemm_psd(false, dX_, dY_, R_, true, true);
+        gemm_psd(dX_, dY_, R_, true, true);
       upload_scalar(S_BETAMU, mw::mul(beta, mu_));
       add_diagonal(R_, S_BETAMU);
     }
     {
       // Z = Symmetrize(X^{-1} (PrimalResidues Y - R))
       Timer t(this, "searchDirection.Z");
-      gemm_psd(false, PR_, Y_, Z_, false, false);
-      sub_inplace(Z_, R_);
-      cholesky_solve_X(Z_);
+      gemm_psd(PR_, Y_, Z_, false, false, &R_, true); // Z^T = (PR Y - R)^T
+      cholesky_solve_X_transposed(Z_);
       symmetrize(Z_, false);
     }
     {
@@ -1006,19 +1040,11 @@ private:
     {
       // dY = Symmetrize(X^{-1} (R - dX Y))
       Timer t(this, "searchDirection.dY");
-      gemm_psd(false, dX_, Y_, dY_, false, false);
-      sub_inplace(dY_, R_);
-      cholesky_solve_X(dY_);
+      gemm_psd(dX_, Y_, dY_, false, false, &R_, true); // dY^T = (dX Y - R)^T
+      cholesky_solve_X_transposed(dY_);
       symmetrize(dY_, true);
     }
   }
-  void sub_inplace(DevArray &A, const DevArray &B)
-  {
-    mw::Ptr a = A.ptr();
-    mw::CPtr b = B.cptr();
-    foreach(psd_elems_, [=] __device__(size_t i) { mw::store<NL>(a, i, mw::sub(mw::load<NL>(a, i), mw::load<NL>(b, i))); });
-  }
-
   // corrector_centering_parameter.cxx:12-31 + frobenius_product_of_sums.cxx:6-31
   M corrector_centering_parameter(bool feasible)
   {
@@ -1040,9 +1066,14 @@ private:
   {
     Timer t(this, name);
     copy(dM, W_);
+    // W = L^{-1} dM L^{-T} (lower_triangular_inverse_congruence.cxx:4-16): W1 = dM L^{-T}, then
+    // W = (W1^T L^{-T}) since the result is symmetric — both solves run on rows
     launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
-    launch(k_trsm_lln<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
-    launch(k_min_eig<NL>, dim3(2 * Jl_), dim3(EIG_T), stream_, psd(W_), vecn(eigD_), vecn(eigE_), lam_.ptr());
+    launch(k_transpose<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(W_));
+    launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
+    launch(k_tridiag<NL>, dim3(2 * Jl_), dim3(EIG_T), stream_, psd(W_), vecn(eigD_), vecn(eigE_));
+    launch(k_tridiag_min<NL>, dim3(cdiv(2 * Jl_, EIG_T)), dim3(EIG_T), stream_, vecn(eigD_), vecn(eigE_), eigF_.p, eigF_.p + psd_rows_local_ + 1,
+           lam_.ptr());
     mw::CPtr lp = lam_.cptr();
     M lambda = reduce<RED_MIN>((size_t)2 * Jl_, [=] __device__(size_t i) { return mw::load<NL>(lp, i); });
     if(Jl_ == 0)
@@ -1125,7 +1156,7 @@ private:
     initialize_schur_complement_solver();
     {
       Timer t(this, "XY");
-      gemm_psd(false, X_, Y_, mXY_, true, false);
+      gemm_psd(X_, Y_, mXY_, true, false);
     }
     {
       Timer t(this, "mu");

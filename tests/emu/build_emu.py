@@ -21,11 +21,28 @@ FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-x", "c++", "-I" + os.path.j
          "-Wno-unknown-pragmas", "-Wno-attributes"]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _digest(deps):
+    import hashlib
+    h = hashlib.sha1()
+    for d in sorted(deps):
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, digest):
+    """An object is fresh only if it was compiled from exactly the current sources (a content
+    hash taken when its build started), so edits made while a compile is in flight are caught."""
+    stamp = target + ".stamp"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != digest
+
+
+def _mark(target, digest):
+    with open(target + ".stamp", "w") as f:
+        f.write(digest)
 
 
 def _run(cmd):
@@ -40,20 +57,25 @@ def build(force=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu.hpp"),
                                                                  os.path.join(HERE, "hip_emu.cpp"),
                                                                  os.path.join(ROOT, "include", "sdpb_hip.h")]
-    jobs, objs = [], []
+    digest = _digest(deps)
+    jobs, objs, todo = [], [], []
     for nl in LIMBS:
         obj = os.path.join(OUT, f"solver_{nl}.o")
         objs.append(obj)
-        if force or _stale(obj, deps):
+        if force or _stale(obj, digest):
+            todo.append(obj)
             jobs.append([CXX, *FLAGS, f"-DSDPB_NL={nl}", "-c", os.path.join(CSRC, "solver_nl.hip"), "-o", obj])
     for src, name in ((os.path.join(CSRC, "capi.hip"), "capi.o"), (os.path.join(HERE, "hip_emu.cpp"), "hip_emu.o")):
         obj = os.path.join(OUT, name)
         objs.append(obj)
-        if force or _stale(obj, deps):
+        if force or _stale(obj, digest):
+            todo.append(obj)
             jobs.append([CXX, *FLAGS, "-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=8) as ex:
             list(ex.map(_run, jobs))
+        for o in todo:
+            _mark(o, digest)
     if jobs or not os.path.exists(LIB):
         _run([CXX, "-shared", "-fPIC", "-fopenmp", "-o", LIB, *objs])
     return LIB

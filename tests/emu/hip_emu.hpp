@@ -112,6 +112,12 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind
   std::memmove(d, s, n);
   return hipSuccess;
 }
+inline hipError_t hipMemcpy2D(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind)
+{
+  for(size_t r = 0; r < height; ++r)
+    std::memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+  return hipSuccess;
+}
 inline hipError_t hipMemset(void *d, int v, size_t n)
 {
   std::memset(d, v, n);

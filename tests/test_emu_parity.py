@@ -46,3 +46,16 @@ def test_emulated_int_syrk_is_exact():
                 assert got[i + j * cols] == want[j + i * cols], (i, j)
             else:
                 assert got[i + j * cols] == 0
+
+
+def test_blocked_cholesky_Q_and_Q_solves_with_ragged_panels(monkeypatch):
+    """N=20 with a panel width of 7 exercises the multi-panel Cholesky(Q) / SolveAfter path
+    (diagonal-block inversion, panel product, trailing update, blocked substitutions)."""
+    monkeypatch.setenv("SDPB_HIP_Q_PANEL", "7")
+    sdp, meta, iters, _ = parity.load_case("singlet_cT")
+    s = SDPSolver(sdp, meta["precision"], meta["params"], lib_path=libs.emu_lib())
+    for rec in iters[:3]:
+        assert not s.iterate()
+        bad, _ = parity.compare_iteration(s.scalars(), rec)
+        assert not bad, (rec["iteration"], bad)
+    s.close()
