@@ -53,6 +53,16 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     path = path or DEFAULT_LIB
     if path in _libs:
         return _libs[path]
+    # One HIP runtime per process: PyTorch's ROCm wheel bundles its own libamdhip64 (same
+    # soname).  If torch is loaded AFTER this library the process ends up with two runtimes and
+    # torch sees "no GPUs"; loaded first, the dynamic linker binds this library to torch's copy.
+    # Processes that also use torch.distributed (bench.py, sdpb_amd/distributed.py) therefore
+    # import torch first; do it here so the order never depends on the caller.
+    if os.environ.get("SDPB_AMD_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(path):
         raise SDPBError(3, f"{path} not found: build the HIP extension first "
                            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")

@@ -117,3 +117,40 @@ def test_errors_name_the_block_like_the_reference():
     assert e.value.code == 1
     assert "Block_Diagonal_Matrix X, block index = 0, parity = 0" in str(e.value)
     s.close()
+
+
+def test_rccl_callbacks_alias_device_memory_zero_copy():
+    """The multi-GPU exchange path hands raw device pointers to torch.distributed (backend
+    nccl = RCCL).  With a 1-rank group a SUM all-reduce and an all-gather must leave the
+    bytes intact — and the aliasing tensor must really be the library's memory."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from sdpb_amd.distributed import make_collectives, tensor_from_pointer
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        allreduce, allgather = make_collectives(dev)
+        a = torch.arange(4096, dtype=torch.int64, device=dev) * 1234567
+        view = tensor_from_pointer(a.data_ptr(), a.numel() * 8, dev)
+        view[0] = 77  # writes through to `a`: zero copy
+        torch.cuda.synchronize()
+        assert int(a[0].item() & 0xFF) == 77
+        ref = a.clone()
+        assert allreduce(a.data_ptr(), a.numel()) == 0
+        assert torch.equal(a, ref)
+        send = torch.randint(0, 255, (1000,), dtype=torch.uint8, device=dev)
+        recv = torch.zeros(1000, dtype=torch.uint8, device=dev)
+        assert allgather(send.data_ptr(), recv.data_ptr(), 1000) == 0
+        assert torch.equal(send, recv)
+    finally:
+        dist.destroy_process_group()
