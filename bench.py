@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SDPB_BENCH_WORKLOAD", "C4"))
     ap.add_argument("--scale", type=float, default=float(os.environ.get("SDPB_BENCH_SCALE", "1.0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="developer aid, NOT a measurement: run rank 0 of an N-rank job on one GPU with the "
+                         "other ranks' contributions faked as copies of its own (per-rank timing without xGMI)")
     args = ap.parse_args()
 
     import torch
@@ -75,6 +78,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    sim = args.simulate_world if world == 1 else 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -87,11 +91,26 @@ def main():
     precision = cfg["precision"]
     sdp, source = synthetic.make_lazy(cfg["dims"], cfg["num_points"], cfg["N"], precision, cfg["seed"])
     t_setup = time.time()
-    solver = SDPSolver(sdp, precision, device=local_rank, rank=rank, world_size=world, upload_all_blocks=False,
+    solver = SDPSolver(sdp, precision, device=local_rank, rank=rank, world_size=sim or world, upload_all_blocks=False,
                        block_source=source)
     if world > 1:
         from sdpb_amd.distributed import make_collectives
         solver.set_collectives(*make_collectives(device))
+    elif sim:
+        from sdpb_amd.distributed import tensor_from_pointer
+
+        def fake_allreduce(ptr, count):
+            tensor_from_pointer(ptr, count * 8, device).view(torch.int64).mul_(sim)
+            torch.cuda.synchronize(device)
+            return 0
+
+        def fake_allgather(send, recv, nbytes):
+            r = tensor_from_pointer(recv, nbytes * sim, device).view(sim, nbytes)
+            r.copy_(tensor_from_pointer(send, nbytes, device).unsqueeze(0).expand(sim, nbytes))
+            torch.cuda.synchronize(device)
+            return 0
+
+        solver.set_collectives(fake_allreduce, fake_allgather)
     t_setup = time.time() - t_setup
 
     def barrier():
@@ -155,6 +174,8 @@ def main():
             "stage_ms_per_step": stages,
             "setup_s": t_setup,
         }
+        if sim:
+            out["SIMULATED_WORLD_NOT_A_MEASUREMENT"] = sim
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, precision)
         print(json.dumps(out), flush=True)

@@ -94,20 +94,47 @@ template <int NL, int OP, class F> __global__ void __launch_bounds__(WG) k_reduc
 }
 
 // ---------------------------------------------------------------------------
-// Cholesky, lower, in place; one workgroup per matrix.  Also writes 1/L_ii.
-// Replaces El::Cholesky(LOWER, .) at cholesky_decomposition.cxx:17 (X, Y blocks)
-// and compute_Q.cxx:31 (Schur blocks); the diagonal block of the blocked
-// Cholesky(Q) (initialize_schur_complement_solver.cxx:98) uses it too.
-// fail[q] = 1 + (index of the non-positive pivot) if the matrix is not PD.
+// Blocked triangular machinery (batched).  Every dependent multi-word multiply-add
+// costs ~1.5 us of latency, so anything triangular is processed in panels of
+// PB = 32 columns: the PB x PB diagonal factor is factored AND inverted inside LDS
+// (k_chol_inv_lds), after which panel solves, trailing updates and all later
+// triangular solves are short dot products spread over many lanes.  `Li` arrays have
+// the shape of the factor L and hold, in each diagonal PB x PB block, the inverse of
+// that block of L.  Panel p covers rows/columns [PB*p, min(PB*(p+1), n)).
+// Replaces El::Cholesky(LOWER/UPPER) (cholesky_decomposition.cxx:17, compute_Q.cxx:31,
+// initialize_schur_complement_solver.cxx:98) and El::Trsm (compute_A_X_inv.cxx:21,
+// cholesky_solve.cxx:9, compute_Q.cxx:48, lower_triangular_inverse_congruence.cxx:8-13,
+// lower_triangular_solve.hxx:10, lower_triangular_transpose_solve.cxx:6).
 // ---------------------------------------------------------------------------
-template <int NL> __global__ void __launch_bounds__(WG) k_chol_lower(Batch A, Batch invd, int *fail)
+#ifndef SDPB_PB
+#define SDPB_PB 32
+#endif
+constexpr int PB = SDPB_PB; // panel width (tests also build a PB = 4 variant to exercise ragged multi-panel paths)
+constexpr int CI_T = 512; // lanes of the diagonal-block kernel
+
+// Diagonal block p of every matrix: A_pp = L L^T in place (upper part zeroed),
+// Li_pp = L^{-1}, invd = 1/L_ii.  fail[q] = 1 + index of a non-positive pivot.
+template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A, Batch invd, Batch Li, int p, int *fail)
 {
   const int q = blockIdx.x;
-  const MatDesc d = A.d[q];
-  const MatDesc dv = invd.d[q];
-  const int n = d.rows, t = threadIdx.x;
+  const MatDesc d = A.d[q], dv = invd.d[q], di = Li.d[q];
+  const int k0 = PB * p, t = threadIdx.x;
+  if(k0 >= d.rows)
+    return;
+  const int n = d.rows - k0 < PB ? d.rows - k0 : PB;
+  __shared__ Mw<NL> sL[PB * (PB + 1) / 2], sI[PB * (PB + 1) / 2];
   __shared__ Mw<NL> s_inv;
   __shared__ int s_fail;
+#define SDPB_PK(r, c) ((c) * n - (c) * ((c)-1) / 2 + ((r) - (c)))
+  for(int idx = t; idx < n * n; idx += CI_T)
+    {
+      const int c = idx / n, r = idx % n;
+      if(r >= c)
+        {
+          sL[SDPB_PK(r, c)] = mat_ld<NL>(A, d, k0 + r, k0 + c);
+          sI[SDPB_PK(r, c)] = r == c ? mw::from_u32<NL>(1) : mw::zero<NL>();
+        }
+    }
   if(t == 0)
     s_fail = 0;
   __syncthreads();
@@ -115,19 +142,15 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_lower(Batch A, Ba
     {
       if(t == 0)
         {
-          const Mw<NL> dj = mat_ld<NL>(A, d, j, j);
+          const Mw<NL> dj = sL[SDPB_PK(j, j)];
           if(mw::is_zero(dj) || dj.neg)
-            s_fail = j + 1;
+            s_fail = k0 + j + 1;
           else
             {
               const Mw<NL> r = mw::rsqrt(dj);
-              Mw<NL> s = mw::mul(dj, r);
-              s = mw::add(s, mw::mul_2exp(mw::mul(r, mw::sub(dj, mw::mul(s, s))), -1));
-              mat_st<NL>(A, d, j, j, s);
-              // 1/s refined from r: inv = r*(2 - s*r)
-              const Mw<NL> inv = mw::mul(r, mw::sub(mw::from_u32<NL>(2), mw::mul(s, r)));
-              s_inv = inv;
-              mw::store<NL>(invd.p, (size_t)dv.off + j, inv);
+              sL[SDPB_PK(j, j)] = mw::mul(dj, r);
+              s_inv = r;
+              mw::store<NL>(invd.p, (size_t)dv.off + k0 + j, r);
             }
         }
       __syncthreads();
@@ -138,104 +161,166 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_lower(Batch A, Ba
           return;
         }
       const Mw<NL> inv = s_inv;
-      for(int i = j + 1 + t; i < n; i += WG)
-        mat_st<NL>(A, d, i, j, mw::mul(mat_ld<NL>(A, d, i, j), inv));
+      for(int i = j + 1 + t; i < n; i += CI_T)
+        sL[SDPB_PK(i, j)] = mw::mul(sL[SDPB_PK(i, j)], inv);
       __syncthreads();
       const int m = n - j - 1;
-      for(int idx = t; idx < m * m; idx += WG)
+      for(int idx = t; idx < m * m; idx += CI_T)
         {
           const int c = j + 1 + idx / m, r = j + 1 + idx % m;
           if(r >= c)
-            mat_st<NL>(A, d, r, c, mw::fms(mat_ld<NL>(A, d, r, j), mat_ld<NL>(A, d, c, j), mat_ld<NL>(A, d, r, c)));
+            sL[SDPB_PK(r, c)] = mw::fms(sL[SDPB_PK(r, j)], sL[SDPB_PK(c, j)], sL[SDPB_PK(r, c)]);
         }
       __syncthreads();
     }
-  // El::Cholesky leaves the other triangle untouched; callers here expect zeros
-  for(int idx = t; idx < n * n; idx += WG)
+  // inverse by forward substitution on the identity, one team of G lanes per column:
+  //   x_k = x_k / L_kk ; x_i -= L_ik x_k (i > k)
+  const int G = CI_T / PB, c = t / G, g = t % G;
+  for(int k = 0; k < n; ++k)
     {
-      const int c = idx / n, r = idx % n;
-      if(r < c)
-        mat_st<NL>(A, d, r, c, mw::zero<NL>());
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Triangular solves with many independent right-hand sides: one lane per RHS ROW, so
-// that consecutive lanes read consecutive addresses (coalesced).  Column-wise solves of
-// the reference (El::Trsm LEFT: compute_A_X_inv.cxx:21, cholesky_solve.cxx:9) are run on
-// the transposed operand.  L lower, invd = 1/diag(L).  grid = (ceil(rows/WG), batch)
-// ---------------------------------------------------------------------------
-// X := X L^{-T}   (El::Trsm RIGHT,LOWER,TRANSPOSE; lower_triangular_inverse_
-// congruence.cxx:8).  With B stored transposed (N x P_j) this is also
-// schur_off_diagonal = L^{-1} B (compute_Q.cxx:48): P^T = B^T L^{-T}; one lane per
-// row, rows are contiguous so every load is coalesced.
-template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt(Batch L, Batch invd, Batch X)
-{
-  const int q = blockIdx.y;
-  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
-  const int r = blockIdx.x * WG + threadIdx.x;
-  if(r >= dx.rows)
-    return;
-  const int n = dl.rows;
-  for(int j = 0; j < n; ++j)
-    {
-      Mw<NL> acc = mat_ld<NL>(X, dx, r, j);
-      for(int k = 0; k < j; ++k)
-        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, j, k), acc);
-      mat_st<NL>(X, dx, r, j, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + j)));
-    }
-}
-
-// X := X L^{-1}: the second half of cholesky_solve (cholesky_solve.cxx:9) applied to the
-// transposed right-hand side, (L^{-T} W)^T = W^T L^{-1}; one lane per row, coalesced.
-template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rln(Batch L, Batch invd, Batch X)
-{
-  const int q = blockIdx.y;
-  const MatDesc dl = L.d[q], dv = invd.d[q], dx = X.d[q];
-  const int r = blockIdx.x * WG + threadIdx.x;
-  if(r >= dx.rows)
-    return;
-  const int n = dl.rows;
-  for(int j = n - 1; j >= 0; --j)
-    {
-      Mw<NL> acc = mat_ld<NL>(X, dx, r, j);
-      for(int k = j + 1; k < n; ++k)
-        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k, j), acc);
-      mat_st<NL>(X, dx, r, j, mw::mul(acc, mw::load<NL>(invd.p, (size_t)dv.off + j)));
-    }
-}
-
-// Single right-hand side per matrix: workgroup-cooperative, right-looking.
-// x := L^{-1} x (lower_triangular_solve.hxx:10-17 on dx; first half of
-// El::cholesky::SolveAfter on dy) — TRANS=true: x := L^{-T} x
-// (lower_triangular_transpose_solve.cxx:6-13; second half of SolveAfter).
-template <int NL, bool TRANS> __global__ void __launch_bounds__(WG) k_vec_solve(Batch L, Batch invd, Batch x)
-{
-  const int q = blockIdx.x;
-  const MatDesc dl = L.d[q], dv = invd.d[q], dx = x.d[q];
-  const int n = dl.rows, t = threadIdx.x;
-  __shared__ Mw<NL> s_x;
-  for(int s = 0; s < n; ++s)
-    {
-      const int k = TRANS ? n - 1 - s : s;
-      if(t == 0)
+      if(g == 0 && c <= k && c < n)
+        sI[SDPB_PK(k, c)] = mw::mul(sI[SDPB_PK(k, c)], mw::load<NL>(invd.p, (size_t)dv.off + k0 + k));
+      __syncthreads();
+      if(c <= k && c < n)
         {
-          const Mw<NL> v = mw::mul(mw::load<NL>(x.p, (size_t)dx.off + k), mw::load<NL>(invd.p, (size_t)dv.off + k));
-          mw::store<NL>(x.p, (size_t)dx.off + k, v);
-          s_x = v;
+          const Mw<NL> xk = sI[SDPB_PK(k, c)];
+          if(!mw::is_zero(xk))
+            for(int i = k + 1 + g; i < n; i += G)
+              sI[SDPB_PK(i, c)] = mw::fms(sL[SDPB_PK(i, k)], xk, sI[SDPB_PK(i, c)]);
         }
       __syncthreads();
-      const Mw<NL> xk = s_x;
-      if(!TRANS)
-        for(int i = k + 1 + t; i < n; i += WG)
-          mw::store<NL>(x.p, (size_t)dx.off + i,
-                        mw::fms(mat_ld<NL>(L, dl, i, k), xk, mw::load<NL>(x.p, (size_t)dx.off + i)));
-      else
-        for(int i = t; i < k; i += WG)
-          mw::store<NL>(x.p, (size_t)dx.off + i,
-                        mw::fms(mat_ld<NL>(L, dl, k, i), xk, mw::load<NL>(x.p, (size_t)dx.off + i)));
-      __syncthreads();
     }
+  for(int idx = t; idx < n * n; idx += CI_T)
+    {
+      const int cc = idx / n, r = idx % n;
+      mat_st<NL>(A, d, k0 + r, k0 + cc, r >= cc ? sL[SDPB_PK(r, cc)] : mw::zero<NL>());
+      mat_st<NL>(Li, di, k0 + r, k0 + cc, r >= cc ? sI[SDPB_PK(r, cc)] : mw::zero<NL>());
+    }
+#undef SDPB_PK
+}
+
+// Tile helper shared by the panel kernels: a workgroup owns TR = 8 rows x PB columns;
+// lane t -> (row t % 8, column t / 8), so consecutive lanes read consecutive rows.
+constexpr int TR = WG / PB;
+
+// Cholesky panel solve: A(r, panel p) := A(r, panel p) * Li_pp^T for the rows below the
+// diagonal block, and zero the part of the panel above it.   grid = (row tiles, batch)
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch A, Batch Li, int p)
+{
+  const int q = blockIdx.y;
+  const MatDesc d = A.d[q], di = Li.d[q];
+  const int k0 = PB * p;
+  if(k0 >= d.rows)
+    return;
+  const int nb = d.rows - k0 < PB ? d.rows - k0 : PB;
+  const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
+  const int r = k0 + nb + blockIdx.x * TR + rl;
+  __shared__ Mw<NL> tile[TR][PB];
+  const bool ok = r < d.rows && j < nb;
+  if(blockIdx.x * TR >= d.rows - k0 - nb && blockIdx.x * TR >= k0)
+    return;
+  if(ok)
+    tile[rl][j] = mat_ld<NL>(A, d, r, k0 + j);
+  // rows above the diagonal block: upper triangle is zero in a lower factor
+  const int ru = blockIdx.x * TR + rl;
+  if(ru < k0 && j < nb)
+    mat_st<NL>(A, d, ru, k0 + j, mw::zero<NL>());
+  __syncthreads();
+  if(!ok)
+    return;
+  Mw<NL> acc = mw::zero<NL>();
+  for(int j2 = 0; j2 <= j; ++j2)
+    acc = mw::fma(tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2), acc);
+  mat_st<NL>(A, d, r, k0 + j, acc);
+}
+
+// Trailing update of the blocked Cholesky: A22(i,j) -= sum_k A21(i,k) A21(j,k), i >= j,
+// with A21 = rows below panel p, columns of panel p.   grid = (lower tiles, batch)
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p)
+{
+  const int q = blockIdx.y;
+  const MatDesc d = A.d[q];
+  const int k0 = PB * p;
+  if(k0 >= d.rows)
+    return;
+  const int nb = d.rows - k0 < PB ? d.rows - k0 : PB;
+  const int b0 = k0 + nb, M = d.rows - b0;
+  const int tiles = (M + 15) / 16;
+  int tile = blockIdx.x;
+  if(M <= 0 || tile >= tiles * (tiles + 1) / 2)
+    return;
+  int ti = 0;
+  while((ti + 1) * (ti + 2) / 2 <= tile)
+    ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
+  if(i >= M || j > i)
+    return;
+  Mw<NL> acc = mat_ld<NL>(A, d, b0 + i, b0 + j);
+  for(int k = 0; k < nb; ++k)
+    acc = mw::fms(mat_ld<NL>(A, d, b0 + i, k0 + k), mat_ld<NL>(A, d, b0 + j, k0 + k), acc);
+  mat_st<NL>(A, d, b0 + i, b0 + j, acc);
+}
+
+// X := X L^{-T}, panel p (forward over panels):
+//   T = X(:,panel p) - X(:,cols < k0) L(panel p, cols < k0)^T ;  X(:,panel p) = T Li_pp^T
+// One lane per (row, column of the panel); rows are the independent right-hand sides
+// (with B stored transposed this is schur_off_diagonal = L^{-1} B, compute_Q.cxx:48).
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p)
+{
+  const int q = blockIdx.y;
+  const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
+  const int k0 = PB * p;
+  if(k0 >= dl.rows || (int)(blockIdx.x * TR) >= dx.rows)
+    return;
+  const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
+  const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
+  const int r = blockIdx.x * TR + rl;
+  __shared__ Mw<NL> tile[TR][PB];
+  const bool ok = r < dx.rows && j < nb;
+  if(ok)
+    {
+      Mw<NL> acc = mat_ld<NL>(X, dx, r, k0 + j);
+      for(int k = 0; k < k0; ++k)
+        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k0 + j, k), acc);
+      tile[rl][j] = acc;
+    }
+  __syncthreads();
+  if(!ok)
+    return;
+  Mw<NL> acc = mw::zero<NL>();
+  for(int j2 = 0; j2 <= j; ++j2)
+    acc = mw::fma(tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2), acc);
+  mat_st<NL>(X, dx, r, k0 + j, acc);
+}
+// X := X L^{-1}, panel p (backward over panels):
+//   T = X(:,panel p) - X(:,cols >= k0+nb) L(rows >= k0+nb, panel p) ;  X(:,panel p) = T Li_pp
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rln_panel(Batch L, Batch Li, Batch X, int p)
+{
+  const int q = blockIdx.y;
+  const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
+  const int k0 = PB * p, n = dl.rows;
+  if(k0 >= n || (int)(blockIdx.x * TR) >= dx.rows)
+    return;
+  const int nb = n - k0 < PB ? n - k0 : PB;
+  const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
+  const int r = blockIdx.x * TR + rl;
+  __shared__ Mw<NL> tile[TR][PB];
+  const bool ok = r < dx.rows && j < nb;
+  if(ok)
+    {
+      Mw<NL> acc = mat_ld<NL>(X, dx, r, k0 + j);
+      for(int k = k0 + nb; k < n; ++k)
+        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k, k0 + j), acc);
+      tile[rl][j] = acc;
+    }
+  __syncthreads();
+  if(!ok)
+    return;
+  Mw<NL> acc = mw::zero<NL>();
+  for(int j2 = j; j2 < nb; ++j2)
+    acc = mw::fma(tile[rl][j2], mat_ld<NL>(Li, di, k0 + j2, k0 + j), acc);
+  mat_st<NL>(X, dx, r, k0 + j, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -318,164 +403,6 @@ template <int NL> __global__ void __launch_bounds__(WG) k_symmetrize(Batch A, in
     mat_st<NL>(A, d, j, i, s);
 }
 
-// C(i,j) -= sum_k A(i,k) A(j,k), i >= j : trailing update of the blocked Cholesky(Q)
-template <int NL> __global__ void __launch_bounds__(WG) k_syrk_down_lower(Batch A, Batch C)
-{
-  const int q = blockIdx.y;
-  const MatDesc da = A.d[q], dc = C.d[q];
-  const int M = dc.rows, K = da.cols;
-  const int tiles = (M + 15) / 16;
-  // lower-triangular tile index -> (ti,tj), tj <= ti
-  int tile = blockIdx.x;
-  if(tile >= tiles * (tiles + 1) / 2)
-    return;
-  int ti = 0;
-  while((ti + 1) * (ti + 2) / 2 <= tile)
-    ++ti;
-  const int tj = tile - ti * (ti + 1) / 2;
-  const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
-  if(i >= M || j > i)
-    return;
-  Mw<NL> acc = mat_ld<NL>(C, dc, i, j);
-  for(int k = 0; k < K; ++k)
-    acc = mw::fms(mat_ld<NL>(A, da, i, k), mat_ld<NL>(A, da, j, k), acc);
-  mat_st<NL>(C, dc, i, j, acc);
-}
-
-// ---------------------------------------------------------------------------
-// Blocked Cholesky(Q) / Q-solve helpers.  The sequential part of a triangular
-// operation costs one dependent multi-word multiply-add (~1.5 us) per step, so the
-// dense N x N factor is processed in panels of nb columns: the nb x nb diagonal
-// factor is inverted once (cooperatively), after which panel solves and the four
-// Q^{-1} applications per iteration are short dot products spread over the chip.
-// ---------------------------------------------------------------------------
-// Cholesky of a small (n <= QS_ROWS) matrix held in LDS: the diagonal blocks of the
-// blocked Cholesky(Q).  Same contract as k_chol_lower (lower factor in place, upper
-// part zeroed, 1/L_ii to invd, fail flag); the packed lower triangle lives in LDS so
-// each of the n dependent column steps costs LDS rather than L2 latency.
-template <int NL> __global__ void __launch_bounds__(WG) k_chol_lower_lds(Batch A, Batch invd, int *fail)
-{
-  constexpr int MAXN = 32;
-  const int q = blockIdx.x;
-  const MatDesc d = A.d[q];
-  const MatDesc dv = invd.d[q];
-  const int n = d.rows, t = threadIdx.x;
-  __shared__ Mw<NL> sL[MAXN * (MAXN + 1) / 2];
-  __shared__ Mw<NL> s_inv;
-  __shared__ int s_fail;
-#define SDPB_PK(r, c) ((c) * n - (c) * ((c)-1) / 2 + ((r) - (c)))
-  for(int idx = t; idx < n * n; idx += WG)
-    {
-      const int c = idx / n, r = idx % n;
-      if(r >= c)
-        sL[SDPB_PK(r, c)] = mat_ld<NL>(A, d, r, c);
-    }
-  if(t == 0)
-    s_fail = 0;
-  __syncthreads();
-  for(int j = 0; j < n; ++j)
-    {
-      if(t == 0)
-        {
-          const Mw<NL> dj = sL[SDPB_PK(j, j)];
-          if(mw::is_zero(dj) || dj.neg)
-            s_fail = j + 1;
-          else
-            {
-              const Mw<NL> r = mw::rsqrt(dj);
-              sL[SDPB_PK(j, j)] = mw::mul(dj, r);
-              s_inv = r;
-              mw::store<NL>(invd.p, (size_t)dv.off + j, r);
-            }
-        }
-      __syncthreads();
-      if(s_fail)
-        {
-          if(t == 0)
-            fail[q] = s_fail;
-          return;
-        }
-      const Mw<NL> inv = s_inv;
-      for(int i = j + 1 + t; i < n; i += WG)
-        sL[SDPB_PK(i, j)] = mw::mul(sL[SDPB_PK(i, j)], inv);
-      __syncthreads();
-      const int m = n - j - 1;
-      for(int idx = t; idx < m * m; idx += WG)
-        {
-          const int c = j + 1 + idx / m, r = j + 1 + idx % m;
-          if(r >= c)
-            sL[SDPB_PK(r, c)] = mw::fms(sL[SDPB_PK(r, j)], sL[SDPB_PK(c, j)], sL[SDPB_PK(r, c)]);
-        }
-      __syncthreads();
-    }
-  for(int idx = t; idx < n * n; idx += WG)
-    {
-      const int c = idx / n, r = idx % n;
-      mat_st<NL>(A, d, r, c, r >= c ? sL[SDPB_PK(r, c)] : mw::zero<NL>());
-    }
-#undef SDPB_PK
-}
-
-// Linv = L^{-1} for a batch of small lower-triangular matrices; one workgroup per
-// matrix, the threads of a workgroup are split into n column teams.
-template <int NL> __global__ void __launch_bounds__(WG) k_tri_inverse(Batch L, Batch invd, Batch Linv)
-{
-  const int q = blockIdx.x;
-  const MatDesc dl = L.d[q], dv = invd.d[q], di = Linv.d[q];
-  const int n = dl.rows, t = threadIdx.x;
-  if(n <= 0)
-    return;
-  const int G = WG / n > 0 ? WG / n : 1; // threads per column team
-  // columns handled by this thread: c = t / G (+ multiples of WG/G when n > WG)
-  const int teams = WG / G;
-  for(int idx = t; idx < n * n; idx += WG)
-    {
-      const int r = idx % n, c = idx / n;
-      mat_st<NL>(Linv, di, r, c, r == c ? mw::from_u32<NL>(1) : mw::zero<NL>());
-    }
-  __syncthreads();
-  const int g = t % G;
-  for(int k = 0; k < n; ++k)
-    {
-      const Mw<NL> ik = mw::load<NL>(invd.p, (size_t)dv.off + k);
-      for(int c = t / G; c <= k; c += teams)
-        if(g == 0)
-          mat_st<NL>(Linv, di, k, c, mw::mul(mat_ld<NL>(Linv, di, k, c), ik));
-      __syncthreads();
-      for(int c = t / G; c <= k; c += teams)
-        {
-          const Mw<NL> xk = mat_ld<NL>(Linv, di, k, c);
-          if(mw::is_zero(xk))
-            continue;
-          for(int i = k + 1 + g; i < n; i += G)
-            mat_st<NL>(Linv, di, i, c, mw::fms(mat_ld<NL>(L, dl, i, k), xk, mat_ld<NL>(Linv, di, i, c)));
-        }
-      __syncthreads();
-    }
-}
-// Out(r,j) = sum_{k<=j} A(r,k) * Linv(j,k)   (= A * Linv^T, Linv lower): the panel solve
-// X L^T = A of the blocked Cholesky as a product with the inverted diagonal factor.
-template <int NL> __global__ void __launch_bounds__(WG) k_panel_mul_linvT(Batch A, Batch Linv, Batch Out)
-{
-  const MatDesc da = A.d[0], di = Linv.d[0], dout = Out.d[0];
-  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= (size_t)da.rows * da.cols)
-    return;
-  const int r = (int)(idx % da.rows), j = (int)(idx / da.rows);
-  Mw<NL> acc = mw::zero<NL>();
-  for(int k = 0; k <= j; ++k)
-    acc = mw::fma(mat_ld<NL>(A, da, r, k), mat_ld<NL>(Linv, di, j, k), acc);
-  mat_st<NL>(Out, dout, r, j, acc);
-}
-template <int NL> __global__ void __launch_bounds__(WG) k_copy_mat(Batch Src, Batch Dst)
-{
-  const MatDesc ds = Src.d[0], dd = Dst.d[0];
-  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= (size_t)ds.rows * ds.cols)
-    return;
-  const int r = (int)(idx % ds.rows), c = (int)(idx / ds.rows);
-  mat_st<NL>(Dst, dd, r, c, mat_ld<NL>(Src, ds, r, c));
-}
 // One panel step of the blocked substitution with the Cholesky factor of Q
 // (El::cholesky::SolveAfter, solve_schur_complement_equation.cxx:64):
 //   xp = Linv_pp * rhs[k0..k0+nb)            (TRANS: Linv_pp^T)
@@ -486,7 +413,7 @@ template <int NL> __global__ void __launch_bounds__(WG) k_copy_mat(Batch Src, Ba
 // suffices) and owns QS_ROWS rows of the update; each dot product is split over
 // QS_SEG lanes and reduced through LDS, so the dependent chain per launch is
 // 2*(nb/QS_SEG + QS_SEG) multi-word operations instead of 2*nb.
-constexpr int QS_ROWS = 32, QS_SEG = 8; // QS_ROWS * QS_SEG == WG; nb <= QS_ROWS
+constexpr int QS_ROWS = PB, QS_SEG = WG / PB; // QS_ROWS * QS_SEG == WG; nb <= QS_ROWS
 template <int NL, bool TRANS>
 __global__ void __launch_bounds__(WG) k_qsolve_panel(Batch Q, Batch Linv, mw::Ptr rhs, mw::Ptr out, int k0)
 {
@@ -1026,24 +953,7 @@ __global__ void __launch_bounds__(WG)
 // multi-word precision — monotone from below, quadratically convergent.
 // lam[q] = lambda_min (zero-size matrices write +huge so they never win the MIN).
 // ---------------------------------------------------------------------------
-constexpr int EIG_T = 64;      // one wavefront per matrix
-
-template <int NL> __device__ Mw<NL> eig_reduce_sum(const Mw<NL> &v)
-{
-  __shared__ Mw<NL> sm[EIG_T];
-  const int t = threadIdx.x;
-  sm[t] = v;
-  __syncthreads();
-  for(int s = EIG_T / 2; s > 0; s >>= 1)
-    {
-      if(t < s)
-        sm[t] = mw::add(sm[t], sm[t + s]);
-      __syncthreads();
-    }
-  const Mw<NL> r = sm[0];
-  __syncthreads();
-  return r;
-}
+constexpr int EIG_T = 64; // lanes per workgroup of the one-lane-per-matrix stage
 
 // number of eigenvalues of the tridiagonal (a, b2 = offdiag^2) below x, in fp64
 __device__ inline int sturm_count_f64(const double *a, const double *b2, int n, double x)
@@ -1063,9 +973,27 @@ __device__ inline int sturm_count_f64(const double *a, const double *b2, int n, 
   return cnt;
 }
 
-// Stage 1: Householder tridiagonalisation (EISPACK tred1 organisation), one wavefront
-// per matrix.  D = diagonal, E[1..n) = off-diagonal of the tridiagonal matrix.
-template <int NL> __global__ void __launch_bounds__(EIG_T) k_tridiag(Batch A, Batch D, Batch E)
+// Stage 1: Householder tridiagonalisation (EISPACK tred1 organisation), one workgroup
+// of TRI_T lanes per matrix.  D = diagonal, E[1..n) = off-diagonal of the tridiagonal
+// matrix.  Row dot products are split over teams of lanes and meet in LDS so that the
+// dependent chain per Householder step stays short.
+constexpr int TRI_T = 256;
+template <int NL> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
+{
+  const int t = threadIdx.x;
+  sm[t] = v;
+  __syncthreads();
+  for(int s = TRI_T / 2; s > 0; s >>= 1)
+    {
+      if(t < s)
+        sm[t] = mw::add(sm[t], sm[t + s]);
+      __syncthreads();
+    }
+  const Mw<NL> r = sm[0];
+  __syncthreads();
+  return r;
+}
+template <int NL> __global__ void __launch_bounds__(TRI_T) k_tridiag(Batch A, Batch D, Batch E)
 {
   const int q = blockIdx.x;
   const MatDesc d = A.d[q];
@@ -1073,6 +1001,7 @@ template <int NL> __global__ void __launch_bounds__(EIG_T) k_tridiag(Batch A, Ba
   const int n = d.rows, t = threadIdx.x;
   if(n == 0)
     return;
+  __shared__ Mw<NL> sm[TRI_T];
   __shared__ Mw<NL> s_hinv;
   for(int i = n - 1; i >= 1; --i)
     {
@@ -1084,12 +1013,12 @@ template <int NL> __global__ void __launch_bounds__(EIG_T) k_tridiag(Batch A, Ba
           continue;
         }
       Mw<NL> part = mw::zero<NL>();
-      for(int k = t; k <= l; k += EIG_T)
+      for(int k = t; k <= l; k += TRI_T)
         {
           const Mw<NL> a = mat_ld<NL>(A, d, i, k);
           part = mw::fma(a, a, part);
         }
-      const Mw<NL> h0 = eig_reduce_sum<NL>(part);
+      const Mw<NL> h0 = tri_reduce_sum<NL>(part, sm);
       if(mw::is_zero(h0))
         {
           if(t == 0)
@@ -1109,29 +1038,48 @@ template <int NL> __global__ void __launch_bounds__(EIG_T) k_tridiag(Batch A, Ba
         }
       __syncthreads();
       const Mw<NL> hinv = s_hinv;
-      part = mw::zero<NL>();
-      for(int j = t; j <= l; j += EIG_T)
+      // e[j] = (A_sub u)_j / h with teams of G lanes per row j
+      const int w = l + 1;
+      int G = TRI_T / w;
+      G = G < 1 ? 1 : (G > 8 ? 8 : G);
+      const int teams = TRI_T / G, g = t % G;
+      Mw<NL> fpart = mw::zero<NL>();
+      for(int j0 = 0; j0 < w; j0 += teams)
         {
-          Mw<NL> g = mw::zero<NL>();
-          for(int k = 0; k <= j; ++k)
-            g = mw::fma(mat_ld<NL>(A, d, j, k), mat_ld<NL>(A, d, i, k), g);
-          for(int k = j + 1; k <= l; ++k)
-            g = mw::fma(mat_ld<NL>(A, d, k, j), mat_ld<NL>(A, d, i, k), g);
-          const Mw<NL> ej = mw::mul(g, hinv);
-          mw::store<NL>(E.p, oe + j, ej);
-          part = mw::fma(ej, mat_ld<NL>(A, d, i, j), part);
+          const int j = j0 + t / G;
+          Mw<NL> acc = mw::zero<NL>();
+          if(j < w && t / G < teams)
+            for(int k = g; k < w; k += G)
+              {
+                const Mw<NL> ajk = k <= j ? mat_ld<NL>(A, d, j, k) : mat_ld<NL>(A, d, k, j);
+                acc = mw::fma(ajk, mat_ld<NL>(A, d, i, k), acc);
+              }
+          sm[t] = acc;
+          __syncthreads();
+          if(g == 0 && j < w && t / G < teams)
+            {
+              Mw<NL> sum = sm[t];
+              for(int gg = 1; gg < G; ++gg)
+                sum = mw::add(sum, sm[t + gg]);
+              const Mw<NL> ej = mw::mul(sum, hinv);
+              mw::store<NL>(E.p, oe + j, ej);
+              fpart = mw::fma(ej, mat_ld<NL>(A, d, i, j), fpart);
+            }
+          __syncthreads();
         }
-      const Mw<NL> f = eig_reduce_sum<NL>(part);
+      const Mw<NL> f = tri_reduce_sum<NL>(fpart, sm);
       const Mw<NL> hh = mw::mul_2exp(mw::mul(f, hinv), -1);
-      for(int j = t; j <= l; j += EIG_T)
+      for(int j = t; j < w; j += TRI_T)
         mw::store<NL>(E.p, oe + j, mw::sub(mw::load<NL>(E.p, oe + j), mw::mul(hh, mat_ld<NL>(A, d, i, j))));
       __syncthreads();
-      const int w = l + 1;
-      for(int idx = t; idx < w * w; idx += EIG_T)
+      // rank-2 update of the leading w x w lower triangle (packed index -> (j,k), k <= j)
+      const int cnt = w * (w + 1) / 2;
+      for(int idx = t; idx < cnt; idx += TRI_T)
         {
-          const int j = idx / w, k = idx % w;
-          if(k > j)
-            continue;
+          int j = 0;
+          while((j + 1) * (j + 2) / 2 <= idx)
+            ++j;
+          const int k = idx - j * (j + 1) / 2;
           Mw<NL> v = mat_ld<NL>(A, d, j, k);
           v = mw::fms(mat_ld<NL>(A, d, i, j), mw::load<NL>(E.p, oe + k), v);
           v = mw::fms(mw::load<NL>(E.p, oe + j), mat_ld<NL>(A, d, i, k), v);
@@ -1140,8 +1088,69 @@ template <int NL> __global__ void __launch_bounds__(EIG_T) k_tridiag(Batch A, Ba
       __syncthreads();
     }
   __syncthreads();
-  for(int i = t; i < n; i += EIG_T)
+  for(int i = t; i < n; i += TRI_T)
     mw::store<NL>(D.p, od + i, mat_ld<NL>(A, d, i, i));
+}
+
+// Newton iteration for lambda_min of the tridiagonal (D, E2 = offdiag^2) from below,
+// working at WL limbs (operands are narrowed on load).  Monotone from below in exact
+// arithmetic; quadratically convergent.
+template <int WL, int NL>
+__device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t oe, int n, Mw<WL> &x, double span, int emax,
+                               int backoff_bits)
+{
+  const Mw<WL> minus_one = mw::from_i32<WL>(-1);
+  Mw<WL> prev = x;
+  for(int it = 0; it < 100; ++it)
+    {
+      Mw<WL> S = mw::zero<WL>(), inv = mw::zero<WL>(), tq = mw::zero<WL>();
+      bool overshoot = false;
+      for(int i = 0; i < n; ++i)
+        {
+          Mw<WL> qi = mw::sub(mw::narrow<WL, NL>(mw::load<NL>(D.p, od + i)), x), qp = minus_one;
+          if(i >= 1)
+            {
+              const Mw<WL> u = mw::mul(mw::narrow<WL, NL>(mw::load<NL>(E.p, oe + i)), inv);
+              qi = mw::sub(qi, u);
+              qp = mw::add(minus_one, mw::mul(u, tq));
+            }
+          if(qi.neg || mw::is_zero(qi))
+            {
+              overshoot = true;
+              break;
+            }
+          inv = mw::rcp(qi);
+          tq = mw::mul(qp, inv);
+          S = mw::add(S, tq);
+        }
+      if(overshoot)
+        {
+          // Newton from below never crosses the root in exact arithmetic: a non-positive
+          // pivot after a successful step means x sits within rounding noise of
+          // lambda_min; keep the last point that was below.
+          if(it > 0 && mw::cmp(x, prev) != 0)
+            {
+              x = prev;
+              return;
+            }
+          // the start was not below the spectrum: retreat, 256x further on every retry
+          Mw<WL> back = mw::abs(x);
+          if(mw::is_zero(back))
+            back = mw::mul_2exp(mw::from_double<WL>(span), emax);
+          back.e -= backoff_bits - 8 * it;
+          x = mw::sub(x, back);
+          prev = x;
+          continue;
+        }
+      if(mw::is_zero(S))
+        return;
+      const Mw<WL> delta = mw::neg(mw::rcp(S));
+      prev = x;
+      x = mw::add(x, delta);
+      // quadratic convergence: a step below 2^-(16WL+8) |x| leaves an error ~ step^2
+      if(mw::is_zero(delta) || mw::is_zero(x) || delta.e < x.e - (16 * WL + 8))
+        return;
+    }
 }
 
 // Stage 2: lambda_min of each tridiagonal matrix, one lane per matrix.  fa/fb2 are
@@ -1216,52 +1225,20 @@ __global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double 
     }
   // safely below lambda_min of the exact tridiagonal matrix
   Mw<NL> x = mw::mul_2exp(mw::from_double<NL>(blo - 1e-10 * span - 1e-300), emax);
-  // multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i
-  const Mw<NL> minus_one = mw::from_i32<NL>(-1);
-  Mw<NL> prev = x;
-  for(int it = 0; it < 100; ++it)
-    {
-      Mw<NL> S = mw::zero<NL>(), inv = mw::zero<NL>(), tq = mw::zero<NL>();
-      bool overshoot = false;
-      for(int i = 0; i < n; ++i)
-        {
-          Mw<NL> qi = mw::sub(mw::load<NL>(D.p, od + i), x), qp = minus_one;
-          if(i >= 1)
-            {
-              const Mw<NL> u = mw::mul(mw::load<NL>(E.p, oe + i), inv);
-              qi = mw::sub(qi, u);
-              qp = mw::add(minus_one, mw::mul(u, tq));
-            }
-          if(qi.neg || mw::is_zero(qi))
-            {
-              overshoot = true;
-              break;
-            }
-          inv = mw::rcp(qi);
-          tq = mw::mul(qp, inv);
-          S = mw::add(S, tq);
-        }
-      if(overshoot)
-        {
-          // Newton from below never crosses the root in exact arithmetic: a non-positive
-          // pivot after a successful step means x already sits within rounding noise of
-          // lambda_min.  Before any step it means the fp64 start was not below: back off.
-          if(it > 0 && mw::cmp(x, prev) != 0)
-            break;
-          const Mw<NL> back = mw::mul_2exp(mw::from_double<NL>(span * 1e-6 * (double)(1 << (it < 20 ? it : 20))), emax);
-          x = mw::sub(x, back);
-          prev = x;
-          continue;
-        }
-      if(mw::is_zero(S))
-        break;
-      const Mw<NL> delta = mw::neg(mw::rcp(S));
-      prev = x;
-      x = mw::add(x, delta);
-      // quadratic convergence: a step below 2^-(16NL+8) |x| leaves an error ~ step^2
-      if(mw::is_zero(delta) || mw::is_zero(x) || delta.e < x.e - (16 * NL + 8))
-        break;
-    }
+  // multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i; first at about
+  // half the limbs (quadratic convergence: the early steps need few bits), then one or
+  // two steps at full width
+  constexpr int WL = NL / 2 + 1;
+  Mw<WL> xs = mw::narrow<WL, NL>(x);
+  tridiag_newton<WL, NL>(D, E, od, oe, n, xs, span, emax, 24);
+  {
+    // step a few half-width ulps down so that the full-width stage starts from below
+    Mw<WL> ulps = mw::abs(xs);
+    ulps.e -= 32 * WL - 8;
+    xs = mw::sub(xs, ulps);
+  }
+  x = mw::widen<NL, WL>(xs);
+  tridiag_newton<NL, NL>(D, E, od, oe, n, x, span, emax, 32 * WL - 16);
   mw::store<NL>(lam, q, x);
 }
 

@@ -175,7 +175,7 @@ template <int NL> class Solver : public SolverBase
   std::vector<MatDesc> h_Et_;
   std::vector<MatDesc> h_psd_, h_bases_, h_E_, h_pair_, h_schur_, h_bt_, h_vecP_, h_vecn_;
   // blocked Cholesky(Q): per panel descriptors
-  DevBuf<MatDesc> d_qdiag_, d_qdiagv_, d_qpanel_, d_qtrail_, d_qinv_, d_qtmp_;
+  DevBuf<MatDesc> d_qdiag_, d_rowP_; // diagonal blocks of Q; dx as 1 x P row vectors
   int q_nb_ = 0, q_panels_ = 0;
   int max_n_ = 0, max_q_ = 0, max_P_ = 0;
 
@@ -183,7 +183,7 @@ template <int NL> class Solver : public SolverBase
   DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
   DevArray bases_, E_, Et_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
-  DevArray Qinv_, Qtmp_, qtmpv_;
+  DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_;
   DevBuf<double> eigF_;
@@ -317,30 +317,24 @@ private:
     d_Q_.upload(std::vector<MatDesc>{MatDesc{0, N_, N_, N_, 0}});
     d_vecQ_.upload(std::vector<MatDesc>{MatDesc{0, N_, 1, N_, 0}});
 
-    // blocked Cholesky(Q) panels
-    q_nb_ = N_ <= QS_ROWS ? N_ : QS_ROWS;
-    if(const char *env = std::getenv("SDPB_HIP_Q_PANEL")) // tests: force several (ragged) panels on small N
-      q_nb_ = std::max(4, std::min(std::min(N_, QS_ROWS), std::atoi(env)));
+    // Q is processed in panels of PB columns (kernels.hpp)
+    q_nb_ = PB;
     q_panels_ = (N_ + q_nb_ - 1) / q_nb_;
-    std::vector<MatDesc> qd, qdv, qp, qt, qi, qtm;
+    std::vector<MatDesc> qd;
     for(int p = 0; p < q_panels_; ++p)
       {
-        const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
+        const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0);
         qd.push_back(MatDesc{(unsigned long long)k0 + (unsigned long long)k0 * N_, nb, nb, N_, 0});
-        qdv.push_back(MatDesc{(unsigned long long)k0, nb, 1, nb, 0});
-        qp.push_back(MatDesc{(unsigned long long)(k0 + nb) + (unsigned long long)k0 * N_, rest, nb, N_, 0});
-        qt.push_back(MatDesc{(unsigned long long)(k0 + nb) + (unsigned long long)(k0 + nb) * N_, rest, rest, N_, 0});
-        qi.push_back(MatDesc{(unsigned long long)p * q_nb_ * q_nb_, nb, nb, nb, 0});
-        qtm.push_back(MatDesc{0, rest, nb, rest > 0 ? rest : 1, 0});
       }
     d_qdiag_.upload(qd);
-    d_qdiagv_.upload(qdv);
-    d_qpanel_.upload(qp);
-    d_qtrail_.upload(qt);
-    d_qinv_.upload(qi);
-    d_qtmp_.upload(qtm);
+    {
+      std::vector<MatDesc> rows;
+      for(const MatDesc &v : h_vecP_)
+        rows.push_back(MatDesc{v.off, 1, v.rows, 1, v.aux});
+      d_rowP_.upload(rows);
+    }
 
-    for(DevArray *a : {&X_, &Y_, &Xc_, &Yc_, &dX_, &dY_, &PR_, &mXY_, &R_, &Z_, &W_})
+    for(DevArray *a : {&X_, &Y_, &Xc_, &Yc_, &dX_, &dY_, &PR_, &mXY_, &R_, &Z_, &W_, &LiX_, &LiY_})
       a->alloc(off_psd, NL);
     bases_.alloc(off_bases, NL);
     for(DevArray *a : {&E_, &Et_, &T_, &YQ_})
@@ -348,6 +342,7 @@ private:
     AX_.alloc(off_pair, NL);
     AY_.alloc(off_pair, NL);
     S_.alloc(off_schur, NL);
+    LiS_.alloc(off_schur, NL);
     BT_.alloc(off_bt, NL);
     PT_.alloc(off_bt, NL);
     for(DevArray *a : {&c_, &x_, &dx_, &dres_, &invdS_})
@@ -358,8 +353,7 @@ private:
       a->alloc(N_, NL);
     Q_.alloc((size_t)N_ * N_, NL);
     eigF_.alloc(2 * (off_vecn + 1));
-    Qinv_.alloc((size_t)q_panels_ * q_nb_ * q_nb_, NL);
-    Qtmp_.alloc((size_t)N_ * q_nb_, NL);
+    LiQ_.alloc((size_t)N_ * N_, NL);
     qtmpv_.alloc(N_, NL);
     part_.alloc((size_t)std::max(Jl_, 1) * N_, NL);
     red_.alloc(1024, NL);
@@ -705,12 +699,43 @@ private:
   }
   void clear_flags() { HIP_CHECK(hipMemsetAsync(flags_.p, 0, flags_.n * sizeof(int), stream_)); }
 
+  // A = L L^T in place for a batch (lower factor; Li receives the inverted diagonal blocks)
+  void blocked_cholesky(const Batch &A, const Batch &invd, const Batch &Li, int max_n, int *fail)
+  {
+    const int panels = cdiv(max_n, PB);
+    for(int p = 0; p < panels; ++p)
+      {
+        launch(k_chol_inv_lds<NL>, dim3(A.count), dim3(CI_T), stream_, A, invd, Li, p, fail);
+        const int below = max_n - PB * (p + 1), above = PB * p;
+        const int rows = std::max(below, above);
+        if(rows > 0)
+          launch(k_chol_panel_solve<NL>, dim3(cdiv(rows, TR), A.count), dim3(WG), stream_, A, Li, p);
+        if(below > 0)
+          {
+            const unsigned tiles = cdiv(below, 16);
+            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), stream_, A, p);
+          }
+      }
+  }
+  // X := X L^{-T} (rows of X are the right-hand sides)
+  void trsm_rlt(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n)
+  {
+    for(int p = 0; p < (int)cdiv(max_n, PB); ++p)
+      launch(k_trsm_rlt_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, p);
+  }
+  // X := X L^{-1}
+  void trsm_rln(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n)
+  {
+    for(int p = (int)cdiv(max_n, PB) - 1; p >= 0; --p)
+      launch(k_trsm_rln_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, p);
+  }
+
   // cholesky_decomposition.cxx:5-28
-  void cholesky_psd(const DevArray &A, DevArray &L, DevArray &invd, const char *name)
+  void cholesky_psd(const DevArray &A, DevArray &L, DevArray &invd, DevArray &Li, const char *name)
   {
     copy(A, L);
     clear_flags();
-    launch(k_chol_lower<NL>, dim3(2 * Jl_), dim3(WG), stream_, psd(L), vecn(invd), flags_.p);
+    blocked_cholesky(psd(L), vecn(invd), psd(Li), max_n_, flags_.p);
     check_chol_flags(2 * Jl_, name, false);
   }
   // C = (+/-) A B (+ C) on the PSD-shaped batch; sub != nullptr fuses "- sub"; trans_out
@@ -726,8 +751,8 @@ private:
   // (Xc^{-T} Xc^{-1} A)^T; one lane per row, every load coalesced
   void cholesky_solve_X_transposed(DevArray &At)
   {
-    launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(At));
-    launch(k_trsm_rln<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), psd(At));
+    trsm_rlt(psd(Xc_), psd(LiX_), psd(At), max_n_, max_n_);
+    trsm_rln(psd(Xc_), psd(LiX_), psd(At), max_n_, max_n_);
   }
 
   // ==========================================================================
@@ -755,7 +780,7 @@ private:
     // A_X_inv = (Xc^{-1} E)^T (Xc^{-1} E)      compute_A_X_inv.cxx:18-29
     // computed on the transpose: Tt = E^T Xc^{-T} (row solves), A_X_inv = Tt Tt^T
     copy(Et_, T_);
-    launch(k_trsm_rlt<NL>, dim3(cdiv(max_q_, WG), 2 * Jl_), dim3(WG), stream_, psd(Xc_), vecn(invdX_), etB(T_));
+    trsm_rlt(psd(Xc_), psd(LiX_), etB(T_), max_q_, max_n_);
     launch(k_gemm<NL, false, true>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, etB(T_), etB(T_), pairB(AX_), 0, 0, 1, pairB(AX_), 0, 0);
     // A_Y = E^T (Y E)                           compute_A_Y.cxx:30-45
     launch(k_gemm<NL, false, false>, dim3(cdiv(max_n_, 16) * cdiv(max_q_, 16), 2 * Jl_), dim3(WG), stream_, psd(Y_), eB(E_), eB(YQ_), 0, 0,
@@ -866,13 +891,13 @@ private:
       // compute_Q.cxx:9-61 : L = chol(S) in place, P^T = B^T L^{-T}
       Timer t(this, "initializeSchurComplementSolver.Q.cholesky");
       clear_flags();
-      launch(k_chol_lower<NL>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), flags_.p);
+      blocked_cholesky(schurB(), vecPB(invdS_), Batch{LiS_.ptr(), d_schur_.p, Jl_}, max_P_, flags_.p);
       check_chol_flags(Jl_, "S", true);
     }
     {
       Timer t(this, "initializeSchurComplementSolver.Q.solve");
       copy(BT_, PT_);
-      launch(k_trsm_rlt<NL>, dim3(cdiv(N_, WG), Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), btB(PT_));
+      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_);
     }
     {
       // syrk_Q, compute_Q.cxx:94-132
@@ -945,20 +970,7 @@ private:
   void cholesky_Q()
   {
     int *qflags = flags_.p + 2 * std::max(Jl_, 1);
-    for(int p = 0; p < q_panels_; ++p)
-      {
-        Batch dg{Q_.ptr(), d_qdiag_.p + p, 1}, dv{invdQ_.ptr(), d_qdiagv_.p + p, 1}, iv{Qinv_.ptr(), d_qinv_.p + p, 1};
-        launch(k_chol_lower_lds<NL>, dim3(1), dim3(WG), stream_, dg, dv, qflags);
-        launch(k_tri_inverse<NL>, dim3(1), dim3(WG), stream_, dg, dv, iv);
-        const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
-        if(rest <= 0)
-          continue;
-        Batch pn{Q_.ptr(), d_qpanel_.p + p, 1}, tr{Q_.ptr(), d_qtrail_.p + p, 1}, tm{Qtmp_.ptr(), d_qtmp_.p + p, 1};
-        launch(k_panel_mul_linvT<NL>, dim3(cdiv((size_t)rest * nb, WG)), dim3(WG), stream_, pn, iv, tm);
-        launch(k_copy_mat<NL>, dim3(cdiv((size_t)rest * nb, WG)), dim3(WG), stream_, tm, pn);
-        const unsigned tiles = cdiv(rest, 16);
-        launch(k_syrk_down_lower<NL>, dim3(tiles * (tiles + 1) / 2, 1), dim3(WG), stream_, pn, tr);
-      }
+    blocked_cholesky(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags);
     HIP_CHECK(hipStreamSynchronize(stream_));
     int f[4];
     HIP_CHECK(hipMemcpy(f, qflags, sizeof f, hipMemcpyDeviceToHost));
@@ -973,7 +985,7 @@ private:
   {
     {
       Timer t(this, "searchDirection.solve.dx_Linv");
-      launch(k_vec_solve<NL, false>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
+      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, Batch{dx_.ptr(), d_rowP_.p, Jl_}, 1, max_P_); // dx^T L^{-T}
     }
     {
       Timer t(this, "searchDirection.solve.dy_PTdx");
@@ -986,14 +998,14 @@ private:
       for(int p = 0; p < q_panels_; ++p)
         {
           const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
-          Batch iv{Qinv_.ptr(), d_qinv_.p + p, 1};
+          Batch iv{LiQ_.ptr(), d_qdiag_.p + p, 1};
           launch(k_qsolve_panel<NL, false>, dim3(std::max(1u, cdiv(rest, QS_ROWS))), dim3(WG), stream_, QB(), iv, dy_.ptr(), qtmpv_.ptr(),
                  k0);
         }
       for(int p = q_panels_ - 1; p >= 0; --p)
         {
           const int k0 = p * q_nb_;
-          Batch iv{Qinv_.ptr(), d_qinv_.p + p, 1};
+          Batch iv{LiQ_.ptr(), d_qdiag_.p + p, 1};
           launch(k_qsolve_panel<NL, true>, dim3(std::max(1u, cdiv(k0, QS_ROWS))), dim3(WG), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(), k0);
         }
     }
@@ -1003,7 +1015,7 @@ private:
     }
     {
       Timer t(this, "searchDirection.solve.dx_LTinv");
-      launch(k_vec_solve<NL, true>, dim3(Jl_), dim3(WG), stream_, schurB(), vecPB(invdS_), vecPB(dx_));
+      trsm_rln(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, Batch{dx_.ptr(), d_rowP_.p, Jl_}, 1, max_P_); // dx^T L^{-1}
     }
   }
 
@@ -1062,16 +1074,16 @@ private:
   }
 
   // step_length.cxx:27-46
-  M step_length(const DevArray &Lc, const DevArray &invd, const DevArray &dM, const char *name)
+  M step_length(const DevArray &Lc, const DevArray &Li, const DevArray &dM, const char *name)
   {
     Timer t(this, name);
     copy(dM, W_);
     // W = L^{-1} dM L^{-T} (lower_triangular_inverse_congruence.cxx:4-16): W1 = dM L^{-T}, then
     // W = (W1^T L^{-T}) since the result is symmetric — both solves run on rows
-    launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
+    trsm_rlt(psd(Lc), psd(Li), psd(W_), max_n_, max_n_);
     launch(k_transpose<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(W_));
-    launch(k_trsm_rlt<NL>, dim3(cdiv(max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(Lc), vecn(invd), psd(W_));
-    launch(k_tridiag<NL>, dim3(2 * Jl_), dim3(EIG_T), stream_, psd(W_), vecn(eigD_), vecn(eigE_));
+    trsm_rlt(psd(Lc), psd(Li), psd(W_), max_n_, max_n_);
+    launch(k_tridiag<NL>, dim3(2 * Jl_), dim3(TRI_T), stream_, psd(W_), vecn(eigD_), vecn(eigE_));
     launch(k_tridiag_min<NL>, dim3(cdiv(2 * Jl_, EIG_T)), dim3(EIG_T), stream_, vecn(eigD_), vecn(eigE_), eigF_.p, eigF_.p + psd_rows_local_ + 1,
            lam_.ptr());
     mw::CPtr lp = lam_.cptr();
@@ -1207,8 +1219,8 @@ private:
       compute_search_direction(beta_corrector_, true);
     }
     update_cond_numbers();
-    primal_step_length_ = step_length(Xc_, invdX_, dX_, "stepLength(XCholesky)");
-    dual_step_length_ = step_length(Yc_, invdY_, dY_, "stepLength(YCholesky)");
+    primal_step_length_ = step_length(Xc_, LiX_, dX_, "stepLength(XCholesky)");
+    dual_step_length_ = step_length(Yc_, LiY_, dY_, "stepLength(YCholesky)");
     if(feasible)
       {
         primal_step_length_ = mw::min(primal_step_length_, dual_step_length_);
@@ -1243,8 +1255,8 @@ public:
     compute_objectives();
     {
       Timer t(this, "choleskyDecomposition");
-      cholesky_psd(X_, Xc_, invdX_, "X");
-      cholesky_psd(Y_, Yc_, invdY_, "Y");
+      cholesky_psd(X_, Xc_, invdX_, LiX_, "X");
+      cholesky_psd(Y_, Yc_, invdY_, LiY_, "Y");
     }
     compute_bilinear_pairings();
     compute_dual_residues_and_error();

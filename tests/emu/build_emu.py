@@ -15,9 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sdpb_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
-LIMBS = (6, 10, 16, 18, 24, 26, 34)
+# only the mantissa widths the CPU tests use (the factories are weak symbols): 128, 512, 664, 768 bits
+LIMBS = (6, 18, 24, 26)
 CXX = os.environ.get("CXX", "g++")
-FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-x", "c++", "-I" + os.path.join(HERE, "include"),
+FLAGS = ["-O1", "-std=c++17", "-fPIC", "-fopenmp", "-x", "c++", "-I" + os.path.join(HERE, "include"),
          "-Wno-unknown-pragmas", "-Wno-attributes"]
 
 
@@ -52,25 +53,32 @@ def _run(cmd):
         raise RuntimeError("emu build failed")
 
 
-def build(force=False):
+def build(force=False, panel=None):
+    """panel=None: the product configuration; panel=4: same sources with 4-column panels so that
+    even the small golden SDPs run through the multi-panel Cholesky / triangular-solve paths."""
+    global OUT, LIB
+    base_out = os.path.join(HERE, "_build")
+    OUT = base_out if panel is None else os.path.join(base_out, f"pb{panel}")
+    LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
+    extra = [] if panel is None else [f"-DSDPB_PB={panel}"]
     os.makedirs(OUT, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu.hpp"),
                                                                  os.path.join(HERE, "hip_emu.cpp"),
                                                                  os.path.join(ROOT, "include", "sdpb_hip.h")]
     digest = _digest(deps)
     jobs, objs, todo = [], [], []
-    for nl in LIMBS:
+    for nl in (LIMBS if panel is None else (26,)):
         obj = os.path.join(OUT, f"solver_{nl}.o")
         objs.append(obj)
         if force or _stale(obj, digest):
             todo.append(obj)
-            jobs.append([CXX, *FLAGS, f"-DSDPB_NL={nl}", "-c", os.path.join(CSRC, "solver_nl.hip"), "-o", obj])
+            jobs.append([CXX, *FLAGS, *extra, f"-DSDPB_NL={nl}", "-c", os.path.join(CSRC, "solver_nl.hip"), "-o", obj])
     for src, name in ((os.path.join(CSRC, "capi.hip"), "capi.o"), (os.path.join(HERE, "hip_emu.cpp"), "hip_emu.o")):
         obj = os.path.join(OUT, name)
         objs.append(obj)
         if force or _stale(obj, digest):
             todo.append(obj)
-            jobs.append([CXX, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([CXX, *FLAGS, *extra, "-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=8) as ex:
             list(ex.map(_run, jobs))

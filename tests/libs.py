@@ -17,7 +17,7 @@ def product_lib() -> str:
     return build.LIB if os.path.exists(build.LIB) else build.build()
 
 
-def emu_lib() -> str:
+def emu_lib(panel=None) -> str:
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
-    return build_emu.build()
+    return build_emu.build(panel=panel)

@@ -48,14 +48,16 @@ def test_emulated_int_syrk_is_exact():
                 assert got[i + j * cols] == 0
 
 
-def test_blocked_cholesky_Q_and_Q_solves_with_ragged_panels(monkeypatch):
-    """N=20 with a panel width of 7 exercises the multi-panel Cholesky(Q) / SolveAfter path
-    (diagonal-block inversion, panel product, trailing update, blocked substitutions)."""
-    monkeypatch.setenv("SDPB_HIP_Q_PANEL", "7")
-    sdp, meta, iters, _ = parity.load_case("singlet_cT")
-    s = SDPSolver(sdp, meta["precision"], meta["params"], lib_path=libs.emu_lib())
-    for rec in iters[:3]:
-        assert not s.iterate()
+@pytest.mark.parametrize("name,limit", [("1d-constraints", 5), ("singlet_cT", 3), ("dfibo", None)])
+def test_multi_panel_paths_with_4_column_panels(name, limit):
+    """Same sources built with PB = 4: every Cholesky, triangular solve and Q solve of these small
+    SDPs runs through several (ragged) panels — diagonal-block factor+inverse in LDS, panel solve,
+    trailing update, blocked substitutions."""
+    sdp, meta, iters, out = parity.load_case(name)
+    s = SDPSolver(sdp, meta["precision"], meta["params"], lib_path=libs.emu_lib(panel=4))
+    n = len(iters) if limit is None else limit
+    for rec in iters[:n]:
+        assert not s.iterate(), (name, rec["iteration"], s.terminate_reason)
         bad, _ = parity.compare_iteration(s.scalars(), rec)
         assert not bad, (rec["iteration"], bad)
     s.close()
