@@ -13,6 +13,9 @@
 #pragma once
 #include "dev.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace sdpb
 {
 using mw::Mw;
@@ -763,6 +766,24 @@ __global__ void __launch_bounds__(WG) k_normalize_fx(mw::CPtr PT, size_t count, 
     }
 }
 
+// Lower-triangle 16x16 tiles of an N x N output, enumerated super-block by super-block
+// (8x8 tiles) so that consecutive entries share operand panels.
+inline std::vector<uint32_t> syrk_tile_order(int N)
+{
+  int SB = 8;
+  if(const char *env = std::getenv("SDPB_HIP_SYRK_SB")) // tuning knob: super-block edge in tiles
+    SB = std::max(1, std::atoi(env));
+  const int tiles = (N + 15) / 16, nsb = (tiles + SB - 1) / SB;
+  std::vector<uint32_t> out;
+  for(int bi = 0; bi < nsb; ++bi)
+    for(int bj = 0; bj <= bi; ++bj)
+      for(int ti = bi * SB; ti < std::min(tiles, (bi + 1) * SB); ++ti)
+        for(int tj = bj * SB; tj < std::min(tiles, (bj + 1) * SB); ++tj)
+          if(tj <= ti)
+            out.push_back((uint32_t)ti << 16 | (uint32_t)tj);
+  return out;
+}
+
 // columns K .. 2FX-2 of one signed product folded into the accumulator (see k_syrk_fx)
 template <int FX, int K> struct SyrkColumns
 {
@@ -787,19 +808,24 @@ template <int FX, int K> struct SyrkColumns
 // a (2FX+2)-plane limb-major two's-complement array.  Row chunks of RB rows are
 // staged through LDS (limb-major, so lanes of a wavefront hit distinct banks for
 // the i operand and broadcast the j operand).  accumulate != 0 adds to acc.
+// tile_list[t] = ti << 16 | tj (tj <= ti), built by syrk_tile_order().
 template <int FX, int RB>
-__global__ void __launch_bounds__(WG)
-  k_syrk_fx(const uint32_t *fx, size_t fx_stride, size_t row0, size_t nrows, int N, uint32_t *acc, size_t acc_stride, int accumulate)
+__global__ void __launch_bounds__(WG, (FX <= 16 ? 4 : 2)) // up to 512 bits the accumulators fit 128 VGPRs: 4 waves per SIMD
+  k_syrk_fx(const uint32_t *fx, size_t fx_stride, size_t row0, size_t nrows, int N, uint32_t *acc, size_t acc_stride, int accumulate,
+            const uint32_t *tile_list, int ntile)
 {
   constexpr int W = 2 * FX + 2;
-  const int tiles = (N + 15) / 16;
-  int tile = blockIdx.x;
-  if(tile >= tiles * (tiles + 1) / 2)
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), so XCD x is
+  // given the contiguous range [x*per, (x+1)*per) of `tile_list`, which enumerates the
+  // lower-triangle tiles in 8x8 super-blocks: the workgroups resident on one XCD share a
+  // few row and column panels of P' in that XCD's 4-MiB L2 (placement affects speed
+  // only, never correctness).
+  const int per = (ntile + 7) / 8;
+  const int tile = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+  if((int)(blockIdx.x / 8) >= per || tile >= ntile)
     return;
-  int ti = 0;
-  while((ti + 1) * (ti + 2) / 2 <= tile)
-    ++ti;
-  const int tj = tile - ti * (ti + 1) / 2;
+  const uint32_t tt = tile_list[tile];
+  const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
   const int i = ti * 16 + li, j = tj * 16 + lj;
   __shared__ uint32_t sa[(FX + 1) * RB * 16];

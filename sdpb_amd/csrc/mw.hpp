@@ -350,27 +350,49 @@ template <int W> MW_HD void shl_bits(uint32_t (&x)[W], uint32_t c)
   x[0] = x[0] << c;
 }
 
-// Normalise a (NL+1)-limb magnitude w (value w/2^(32(NL+1)) * 2^e) into r
+// bit i of the result = (w[I0+i] != 0), built as a balanced OR tree (log depth)
+template <int I0, int I1, int W> MW_HD uint32_t nonzero_mask(const uint32_t (&w)[W])
+{
+  if constexpr(I0 == I1)
+    return (w[I0] != 0 ? 1u : 0u) << I0;
+  else
+    {
+      constexpr int MID = (I0 + I1) / 2;
+      return nonzero_mask<I0, MID, W>(w) | nonzero_mask<MID + 1, I1, W>(w);
+    }
+}
+
+// Normalise a (NL+1)-limb magnitude w (value w/2^(32(NL+1)) * 2^e) into r.  The top
+// non-zero limb is located with a mask + clz (log depth), not a serial scan: this sits
+// on the dependent path of every subtraction.
 template <int NL> MW_HD Mw<NL> normalize_w(uint32_t (&w)[NL + 1], int32_t e, uint32_t neg)
 {
-  // leading zero limbs
-  uint32_t zl = 0;
-  bool found = false;
-  uint32_t topw = 0;
-#pragma unroll
-  for(int i = NL; i >= 0; --i)
+  static_assert(NL + 1 <= 64, "mask below is 64 bits wide");
+  uint32_t zl;
+  if constexpr(NL + 1 <= 32)
     {
-      const bool nz = w[i] != 0;
-      if(!found && nz)
-        topw = w[i];
-      if(!found && !nz)
-        zl += 1;
-      found = found || nz;
+      const uint32_t m = nonzero_mask<0, NL, NL + 1>(w);
+      if(m == 0)
+        return zero<NL>();
+      zl = (uint32_t)NL - (31u - clz32(m));
     }
-  if(!found)
-    return zero<NL>();
-  const uint32_t c = clz32(topw);
+  else
+    {
+      uint32_t lo[32], hi[NL + 1 - 32];
+#pragma unroll
+      for(int i = 0; i < 32; ++i)
+        lo[i] = w[i];
+#pragma unroll
+      for(int i = 32; i <= NL; ++i)
+        hi[i - 32] = w[i];
+      const uint32_t mh = nonzero_mask<0, NL - 32, NL + 1 - 32>(hi), ml = nonzero_mask<0, 31, 32>(lo);
+      if((mh | ml) == 0)
+        return zero<NL>();
+      const uint32_t top = mh ? 32u + (31u - clz32(mh)) : (31u - clz32(ml));
+      zl = (uint32_t)NL - top;
+    }
   shl_limbs<NL + 1>(w, zl);
+  const uint32_t c = clz32(w[NL]);
   shl_bits<NL + 1>(w, c);
   Mw<NL> r;
 #pragma unroll
@@ -387,8 +409,9 @@ template <int NL> MW_HD Mw<NL> add(const Mw<NL> &a_in, const Mw<NL> &b_in)
     return b_in;
   if(b_in.e == EZERO)
     return a_in;
-  // big = larger magnitude
-  const bool swap = cmp_abs(a_in, b_in) < 0;
+  // order by exponent only (no limb-by-limb magnitude compare on the dependent path);
+  // with equal exponents a subtraction may come out negative and is then negated
+  const bool swap = a_in.e < b_in.e;
   const Mw<NL> &a = swap ? b_in : a_in;
   const Mw<NL> &b = swap ? a_in : b_in;
   const uint32_t d = (uint32_t)(a.e - b.e);
@@ -434,7 +457,6 @@ template <int NL> MW_HD Mw<NL> add(const Mw<NL> &a_in, const Mw<NL> &b_in)
         }
       return r;
     }
-  // |a| >= |b| : x - y >= 0
   uint32_t borrow = 0;
 #pragma unroll
   for(int i = 0; i <= NL; ++i)
@@ -443,7 +465,21 @@ template <int NL> MW_HD Mw<NL> add(const Mw<NL> &a_in, const Mw<NL> &b_in)
       x[i] = (uint32_t)s;
       borrow = (uint32_t)(s >> 63);
     }
-  return normalize_w<NL>(x, a.e, a.neg);
+  uint32_t sign = a.neg;
+  if(borrow)
+    {
+      // only possible when d == 0 and |b| > |a|: result = -(two's complement)
+      uint32_t carry = 1;
+#pragma unroll
+      for(int i = 0; i <= NL; ++i)
+        {
+          const uint64_t s = (uint64_t)(~x[i]) + carry;
+          x[i] = (uint32_t)s;
+          carry = (uint32_t)(s >> 32);
+        }
+      sign ^= 1u;
+    }
+  return normalize_w<NL>(x, a.e, sign);
 }
 template <int NL> MW_HD Mw<NL> sub(const Mw<NL> &a, const Mw<NL> &b) { return add(a, neg(b)); }
 
@@ -493,8 +529,8 @@ template <int NL> struct RcpMant
   {
     constexpr int NH = NL / 2 + 1;
     const Mw<NL> r0 = widen<NL, NH>(RcpMant<NH>::run(narrow<NH, NL>(man)));
-    const Mw<NL> t = sub(from_u32<NL>(1), mul(man, r0));
-    return add(r0, mul(r0, t));
+    // r0 (2 - man r0): three dependent operations per level
+    return mul(r0, sub(from_u32<NL>(2), mul(man, r0)));
   }
 };
 template <> struct RcpMant<3>
@@ -559,9 +595,9 @@ template <int NL> struct RsqrtMant
   {
     constexpr int NH = NL / 2 + 1;
     const Mw<NL> r0 = widen<NL, NH>(RsqrtMant<NH>::run(narrow<NH, NL>(man)));
-    // r = r0 + r0*(1 - man*r0^2)/2
-    const Mw<NL> t = sub(from_u32<NL>(1), mul(man, mul(r0, r0)));
-    return add(r0, mul_2exp(mul(r0, t), -1));
+    // r0 (3 - man r0^2) / 2: four dependent operations per level
+    const Mw<NL> t = sub(from_u32<NL>(3), mul(man, mul(r0, r0)));
+    return mul_2exp(mul(r0, t), -1);
   }
 };
 template <> struct RsqrtMant<3>

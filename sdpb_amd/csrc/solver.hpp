@@ -185,7 +185,7 @@ template <int NL> class Solver : public SolverBase
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
-  DevBuf<uint32_t> fx_, acc_;
+  DevBuf<uint32_t> fx_, acc_, syrk_tiles_;
   DevBuf<double> eigF_;
   DevBuf<unsigned long long> acc64_;
   DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
@@ -365,6 +365,7 @@ private:
     fx_.alloc(fx_stride_ * (FX + 1));
     acc_stride_ = (size_t)N_ * N_;
     acc_.alloc(acc_stride_ * ACCW);
+    syrk_tiles_.upload(syrk_tile_order(N_));
     if(world_ > 1)
       acc64_.alloc(acc_stride_ * ACCW);
     flags_.alloc((size_t)2 * std::max(Jl_, 1) + 4);
@@ -928,8 +929,8 @@ private:
         {
           // HIP events on the launch stream bracket the dominant kernel (bench.py roofline)
           HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
-          launch(k_syrk_fx<FX, SYRK_RB>, dim3(tiles * (tiles + 1) / 2), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_,
-                 (size_t)0, Ptot_, N_, acc_.p, acc_stride_, 0);
+          launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_,
+                 (size_t)0, Ptot_, N_, acc_.p, acc_stride_, 0, (const uint32_t *)syrk_tiles_.p, (int)(tiles * (tiles + 1) / 2));
           HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
           HIP_CHECK(hipEventSynchronize(ev_syrk1_));
           float ms = 0;
@@ -1438,8 +1439,10 @@ public:
     const size_t as = (size_t)cols * cols;
     acc.alloc(as * ACCW);
     const unsigned tiles = cdiv(cols, 16);
-    launch(k_syrk_fx<FX, SYRK_RB>, dim3(tiles * (tiles + 1) / 2), dim3(WG), stream_, (const uint32_t *)fx.p, cnt, (size_t)0, (size_t)rows,
-           cols, acc.p, as, 0);
+    DevBuf<uint32_t> tl;
+    tl.upload(syrk_tile_order(cols));
+    launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx.p, cnt, (size_t)0, (size_t)rows,
+           cols, acc.p, as, 0, (const uint32_t *)tl.p, (int)(tiles * (tiles + 1) / 2));
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<uint32_t> a = acc.download();
     std::string out;

@@ -61,3 +61,19 @@ def test_multi_panel_paths_with_4_column_panels(name, limit):
         bad, _ = parity.compare_iteration(s.scalars(), rec)
         assert not bad, (rec["iteration"], bad)
     s.close()
+
+
+def test_emulated_library_matches_oracle_on_dim6_blocks():
+    """BASELINE.json config 5 shape (m_j = 6, K_j = 2: 21 (r,s) pairs per block) at reduced size
+    and precision 512: exercises the (r,s) tile decoding of pairings, Schur assembly, constraint
+    sums and the Schur right-hand side against the oracle (tolerance 2^-(p/2))."""
+    from oracle.oracle import Oracle
+    from sdpb_amd.synthetic import make_sdp
+    sdp = make_sdp([6] * 3, [2] * 3, 5, 512, seed=5)
+    s = SDPSolver(sdp, 512, parity.DEFAULT_PARAMS, lib_path=libs.emu_lib())
+    o = Oracle(sdp, 512, parity.DEFAULT_PARAMS, param_prec=0)
+    for it in range(4):
+        assert not s.iterate() and not o.iterate()
+        bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=256)
+        assert not bad, (it + 1, bad)
+    s.close()

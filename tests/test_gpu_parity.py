@@ -86,7 +86,7 @@ def test_gpu_matches_reference_golden(name, limit):
 
 # ---- vs the oracle at the headline precision on a synthetic SDP (SURVEY.md §8d gate:
 # first 10 iterations within 2^-(p/2))
-@pytest.mark.parametrize("cfg,scale,iters", [("C2", 1.0, 10), ("C3", 0.02, 10), ("C4", 0.01, 6)])
+@pytest.mark.parametrize("cfg,scale,iters", [("C2", 1.0, 10), ("C3", 0.02, 10), ("C4", 0.01, 6), ("C5", 0.002, 5)])
 def test_gpu_matches_oracle_on_synthetic(cfg, scale, iters):
     from oracle.oracle import Oracle
     from sdpb_amd.synthetic import config, make_sdp
