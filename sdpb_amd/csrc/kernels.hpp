@@ -804,15 +804,15 @@ template <int FX, int K> struct SyrkColumns
 };
 
 // acc(i,j) (i >= j, tiles of 16x16) = sum_r fx(r,i) * fx(r,j), rows r in
-// [row0, row0+nrows).  fx element (r,n) at r*N + n.  acc element (i,j) at i + j*N in
+// [0, nrows).  fx element (r,n) at r*N + n.  acc element (i,j) at i + j*N in
 // a (2FX+2)-plane limb-major two's-complement array.  Row chunks of RB rows are
 // staged through LDS (limb-major, so lanes of a wavefront hit distinct banks for
-// the i operand and broadcast the j operand).  accumulate != 0 adds to acc.
+// the i operand and broadcast the j operand).
 // tile_list[t] = ti << 16 | tj (tj <= ti), built by syrk_tile_order().
 template <int FX, int RB>
 __global__ void __launch_bounds__(WG, (FX <= 16 ? 4 : 2)) // up to 512 bits the accumulators fit 128 VGPRs: 4 waves per SIMD
-  k_syrk_fx(const uint32_t *fx, size_t fx_stride, size_t row0, size_t nrows, int N, uint32_t *acc, size_t acc_stride, int accumulate,
-            const uint32_t *tile_list, int ntile)
+  k_syrk_fx(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tile_list,
+            int ntile)
 {
   constexpr int W = 2 * FX + 2;
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), so XCD x is
@@ -834,17 +834,18 @@ __global__ void __launch_bounds__(WG, (FX <= 16 ? 4 : 2)) // up to 512 bits the 
 #pragma unroll
   for(int k = 0; k < W; ++k)
     a_acc[k] = 0;
-  for(size_t r0 = 0; r0 < nrows; r0 += RB)
+  for(unsigned r0 = 0; r0 < nrows; r0 += RB)
     {
       // stage: (FX+1) planes x RB rows x 16 columns for each operand
       for(int e = threadIdx.x; e < (FX + 1) * RB * 16; e += WG)
         {
           const int col = e & 15, rr = (e >> 4) % RB, pl = (e >> 4) / RB;
-          const size_t r = r0 + rr;
+          const unsigned r = r0 + rr;
           const int ca = ti * 16 + col, cb = tj * 16 + col;
           const bool okr = r < nrows;
-          sa[e] = (okr && ca < N) ? fx[(size_t)pl * fx_stride + (row0 + r) * (size_t)N + ca] : 0u;
-          sb[e] = (okr && cb < N) ? fx[(size_t)pl * fx_stride + (row0 + r) * (size_t)N + cb] : 0u;
+          const uint32_t *row = fx + (size_t)pl * fx_stride + (size_t)r * (size_t)N;
+          sa[e] = (okr && ca < N) ? row[ca] : 0u;
+          sb[e] = (okr && cb < N) ? row[cb] : 0u;
         }
       __syncthreads();
 #pragma unroll 1
@@ -884,19 +885,9 @@ __global__ void __launch_bounds__(WG, (FX <= 16 ? 4 : 2)) // up to 512 bits the 
   if(i < N && j <= i)
     {
       const size_t o = (size_t)i + (size_t)j * N;
-      uint32_t carry = 0;
 #pragma unroll
       for(int k = 0; k < W; ++k)
-        {
-          uint32_t v = a_acc[k];
-          if(accumulate)
-            {
-              const uint64_t s = (uint64_t)acc[(size_t)k * acc_stride + o] + v + carry;
-              v = (uint32_t)s;
-              carry = (uint32_t)(s >> 32);
-            }
-          acc[(size_t)k * acc_stride + o] = v;
-        }
+        acc[(size_t)k * acc_stride + o] = a_acc[k];
     }
 }
 

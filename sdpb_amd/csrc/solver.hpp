@@ -930,7 +930,7 @@ private:
           // HIP events on the launch stream bracket the dominant kernel (bench.py roofline)
           HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
           launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_,
-                 (size_t)0, Ptot_, N_, acc_.p, acc_stride_, 0, (const uint32_t *)syrk_tiles_.p, (int)(tiles * (tiles + 1) / 2));
+                 (unsigned)Ptot_, N_, acc_.p, acc_stride_, (const uint32_t *)syrk_tiles_.p, (int)(tiles * (tiles + 1) / 2));
           HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
           HIP_CHECK(hipEventSynchronize(ev_syrk1_));
           float ms = 0;
@@ -1441,8 +1441,8 @@ public:
     const unsigned tiles = cdiv(cols, 16);
     DevBuf<uint32_t> tl;
     tl.upload(syrk_tile_order(cols));
-    launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx.p, cnt, (size_t)0, (size_t)rows,
-           cols, acc.p, as, 0, (const uint32_t *)tl.p, (int)(tiles * (tiles + 1) / 2));
+    launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx.p, cnt, (unsigned)rows,
+           cols, acc.p, as, (const uint32_t *)tl.p, (int)(tiles * (tiles + 1) / 2));
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<uint32_t> a = acc.download();
     std::string out;
