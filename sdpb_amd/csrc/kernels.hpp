@@ -19,6 +19,7 @@
 namespace sdpb
 {
 using mw::Mw;
+using mw::Acc;
 constexpr int WG = 256; // workgroup size used by every kernel
 
 template <int NL> MW_HD Mw<NL> mat_ld(const Batch &b, const MatDesc &d, int i, int j)
@@ -85,12 +86,23 @@ template <int NL, int OP, class F> __global__ void __launch_bounds__(WG) k_reduc
 {
   Mw<NL> acc = mw::zero<NL>();
   bool has = false;
-  for(size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < count; i += (size_t)gridDim.x * WG)
+  if(OP == RED_SUM)
     {
-      const Mw<NL> v = f(i);
-      acc = has ? red_combine<NL, OP>(acc, v) : v;
-      has = true;
+      Acc<NL> sum = mw::acc_zero<NL>();
+      for(size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < count; i += (size_t)gridDim.x * WG)
+        {
+          mw::acc_add(sum, f(i));
+          has = true;
+        }
+      acc = mw::acc_result(sum);
     }
+  else
+    for(size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < count; i += (size_t)gridDim.x * WG)
+      {
+        const Mw<NL> v = f(i);
+        acc = has ? red_combine<NL, OP>(acc, v) : v;
+        has = true;
+      }
   const Mw<NL> r = wg_reduce<NL, OP>(acc, has);
   if(threadIdx.x == 0)
     mw::store<NL>(out, blockIdx.x, r);
@@ -231,10 +243,10 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch
   __syncthreads();
   if(!ok)
     return;
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> acc = mw::acc_zero<NL>();
   for(int j2 = 0; j2 <= j; ++j2)
-    acc = mw::fma(tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2), acc);
-  mat_st<NL>(A, d, r, k0 + j, acc);
+    mw::acc_fma(acc, tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2));
+  mat_st<NL>(A, d, r, k0 + j, mw::acc_result(acc));
 }
 
 // Trailing update of the blocked Cholesky: A22(i,j) -= sum_k A21(i,k) A21(j,k), i >= j,
@@ -259,10 +271,11 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
   const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
   if(i >= M || j > i)
     return;
-  Mw<NL> acc = mat_ld<NL>(A, d, b0 + i, b0 + j);
+  Acc<NL> acc = mw::acc_zero<NL>();
+  mw::acc_add(acc, mat_ld<NL>(A, d, b0 + i, b0 + j));
   for(int k = 0; k < nb; ++k)
-    acc = mw::fms(mat_ld<NL>(A, d, b0 + i, k0 + k), mat_ld<NL>(A, d, b0 + j, k0 + k), acc);
-  mat_st<NL>(A, d, b0 + i, b0 + j, acc);
+    mw::acc_fms(acc, mat_ld<NL>(A, d, b0 + i, k0 + k), mat_ld<NL>(A, d, b0 + j, k0 + k));
+  mat_st<NL>(A, d, b0 + i, b0 + j, mw::acc_result(acc));
 }
 
 // X := X L^{-T}, panel p (forward over panels):
@@ -283,18 +296,19 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
   const bool ok = r < dx.rows && j < nb;
   if(ok)
     {
-      Mw<NL> acc = mat_ld<NL>(X, dx, r, k0 + j);
+      Acc<NL> acc = mw::acc_zero<NL>();
+      mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
       for(int k = 0; k < k0; ++k)
-        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k0 + j, k), acc);
-      tile[rl][j] = acc;
+        mw::acc_fms(acc, mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k0 + j, k));
+      tile[rl][j] = mw::acc_result(acc);
     }
   __syncthreads();
   if(!ok)
     return;
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> acc = mw::acc_zero<NL>();
   for(int j2 = 0; j2 <= j; ++j2)
-    acc = mw::fma(tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2), acc);
-  mat_st<NL>(X, dx, r, k0 + j, acc);
+    mw::acc_fma(acc, tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2));
+  mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
 }
 // X := X L^{-1}, panel p (backward over panels):
 //   T = X(:,panel p) - X(:,cols >= k0+nb) L(rows >= k0+nb, panel p) ;  X(:,panel p) = T Li_pp
@@ -312,18 +326,19 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rln_panel(Batch L
   const bool ok = r < dx.rows && j < nb;
   if(ok)
     {
-      Mw<NL> acc = mat_ld<NL>(X, dx, r, k0 + j);
+      Acc<NL> acc = mw::acc_zero<NL>();
+      mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
       for(int k = k0 + nb; k < n; ++k)
-        acc = mw::fms(mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k, k0 + j), acc);
-      tile[rl][j] = acc;
+        mw::acc_fms(acc, mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k, k0 + j));
+      tile[rl][j] = mw::acc_result(acc);
     }
   __syncthreads();
   if(!ok)
     return;
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> acc = mw::acc_zero<NL>();
   for(int j2 = j; j2 < nb; ++j2)
-    acc = mw::fma(tile[rl][j2], mat_ld<NL>(Li, di, k0 + j2, k0 + j), acc);
-  mat_st<NL>(X, dx, r, k0 + j, acc);
+    mw::acc_fma(acc, tile[rl][j2], mat_ld<NL>(Li, di, k0 + j2, k0 + j));
+  mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
 }
 
 // ---------------------------------------------------------------------------
@@ -352,20 +367,19 @@ __global__ void __launch_bounds__(WG)
   const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
   if(i >= M || j >= Nn || (sym && j > i))
     return;
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> sum = mw::acc_zero<NL>();
   for(int k = 0; k < K; ++k)
     {
       const Mw<NL> a = TA ? mat_ld<NL>(A, da, k, i) : mat_ld<NL>(A, da, i, k);
       const Mw<NL> b = TB ? mat_ld<NL>(B, db, j, k) : mat_ld<NL>(B, db, k, j);
-      acc = mw::fma(a, b, acc);
+      mw::acc_fma(sum, a, b, (uint32_t)alpha_neg);
     }
-  if(alpha_neg)
-    acc = mw::neg(acc);
   if(has_sub)
-    acc = mw::sub(acc, mat_ld<NL>(Sub, Sub.d[q], i, j));
+    mw::acc_add(sum, mat_ld<NL>(Sub, Sub.d[q], i, j), 1u);
   const int oi = trans_out ? j : i, oj = trans_out ? i : j;
   if(beta_one)
-    acc = mw::add(acc, mat_ld<NL>(C, dc, oi, oj));
+    mw::acc_add(sum, mat_ld<NL>(C, dc, oi, oj));
+  const Mw<NL> acc = mw::acc_result(sum);
   mat_st<NL>(C, dc, oi, oj, acc);
   if(sym && i != j)
     mat_st<NL>(C, dc, oj, oi, acc);
@@ -428,22 +442,23 @@ __global__ void __launch_bounds__(WG) k_qsolve_panel(Batch Q, Batch Linv, mw::Pt
   if(t < nb)
     sx[t] = mw::load<NL>(rhs, (size_t)k0 + t);
   __syncthreads();
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> acc = mw::acc_zero<NL>();
   if(i < nb)
     for(int k = seg * kper; k < (seg + 1) * kper && k < nb; ++k)
       {
         if(!TRANS && k <= i)
-          acc = mw::fma(mat_ld<NL>(Linv, di, i, k), sx[k], acc);
+          mw::acc_fma(acc, mat_ld<NL>(Linv, di, i, k), sx[k]);
         if(TRANS && k >= i)
-          acc = mw::fma(mat_ld<NL>(Linv, di, k, i), sx[k], acc);
+          mw::acc_fma(acc, mat_ld<NL>(Linv, di, k, i), sx[k]);
       }
-  part[t] = acc;
+  part[t] = mw::acc_result(acc);
   __syncthreads();
   if(t < nb)
     {
-      Mw<NL> s = part[t];
-      for(int g = 1; g < QS_SEG; ++g)
-        s = mw::add(s, part[g * QS_ROWS + t]);
+      Acc<NL> ss = mw::acc_zero<NL>();
+      for(int g = 0; g < QS_SEG; ++g)
+        mw::acc_add(ss, part[g * QS_ROWS + t]);
+      const Mw<NL> s = mw::acc_result(ss);
       sxp[t] = s;
       if(blockIdx.x == 0)
         mw::store<NL>(out, (size_t)k0 + t, s);
@@ -451,26 +466,27 @@ __global__ void __launch_bounds__(WG) k_qsolve_panel(Batch Q, Batch Linv, mw::Pt
   __syncthreads();
   const int first = TRANS ? 0 : k0 + nb, count = TRANS ? k0 : N - k0 - nb;
   const int ri = blockIdx.x * QS_ROWS + i;
-  acc = mw::zero<NL>();
+  acc = mw::acc_zero<NL>();
   if(ri < count)
     {
       const int r = first + ri;
       for(int k = seg * kper; k < (seg + 1) * kper && k < nb; ++k)
         {
           const Mw<NL> l = TRANS ? mat_ld<NL>(Q, dq, k0 + k, r) : mat_ld<NL>(Q, dq, r, k0 + k);
-          acc = mw::fma(l, sxp[k], acc);
+          mw::acc_fma(acc, l, sxp[k]);
         }
     }
   __syncthreads();
-  part[t] = acc;
+  part[t] = mw::acc_result(acc);
   __syncthreads();
   if(seg == 0 && ri < count)
     {
-      Mw<NL> s = part[t];
-      for(int g = 1; g < QS_SEG; ++g)
-        s = mw::add(s, part[g * QS_ROWS + t]);
       const size_t r = (size_t)first + ri;
-      mw::store<NL>(rhs, r, mw::sub(mw::load<NL>(rhs, r), s));
+      Acc<NL> ss = mw::acc_zero<NL>();
+      mw::acc_add(ss, mw::load<NL>(rhs, r));
+      for(int g = 0; g < QS_SEG; ++g)
+        mw::acc_add(ss, part[g * QS_ROWS + t], 1u);
+      mw::store<NL>(rhs, r, mw::acc_result(ss));
     }
 }
 
@@ -532,7 +548,7 @@ __global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Bat
   int c0, r0, row, c1, r1, col;
   decode_p(R, K, c0, r0, row);
   decode_p(C, K, c1, r1, col);
-  Mw<NL> e = mw::zero<NL>();
+  Acc<NL> es = mw::acc_zero<NL>();
   for(int b = 0; b < 2; ++b)
     {
       const MatDesc dx = AX.d[2 * j + b], dy = AY.d[2 * j + b];
@@ -540,14 +556,14 @@ __global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Bat
       // A_Y tile     [cb][rb](r,c) = AY(cb K + c, rb K + r)  (compute_A_Y.cxx:47-64)
 #define AXT(cb, rb) mat_ld<NL>(AX, dx, (cb)*K + row, (rb)*K + col)
 #define AYT(cb, rb) mat_ld<NL>(AY, dy, (cb)*K + col, (rb)*K + row)
-      e = mw::fma(AXT(c0, r1), AYT(c1, r0), e);
-      e = mw::fma(AXT(r0, r1), AYT(c1, c0), e);
-      e = mw::fma(AXT(c0, c1), AYT(r1, r0), e);
-      e = mw::fma(AXT(r0, c1), AYT(r1, c0), e);
+      mw::acc_fma(es, AXT(c0, r1), AYT(c1, r0));
+      mw::acc_fma(es, AXT(r0, r1), AYT(c1, c0));
+      mw::acc_fma(es, AXT(c0, c1), AYT(r1, r0));
+      mw::acc_fma(es, AXT(r0, c1), AYT(r1, c0));
 #undef AXT
 #undef AYT
     }
-  e = mw::mul_2exp(e, -2);
+  const Mw<NL> e = mw::mul_2exp(mw::acc_result(es), -2);
   mat_st<NL>(S, ds, R, C, e);
   if(R != C)
     mat_st<NL>(S, ds, C, R, e);
@@ -591,12 +607,13 @@ __global__ void __launch_bounds__(WG) k_constraint_weighted_sum(Batch bases, mw:
   const int bi = I / rs, i = I % rs, bj = Jc / rs, jj = Jc % rs;
   const int hi = bi > bj ? bi : bj, lo = bi > bj ? bj : bi;
   const size_t voff = (size_t)bl.voff + (size_t)(hi * (hi + 1) / 2 + lo) * bl.K;
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> sum = mw::acc_zero<NL>();
   for(int k = 0; k < bl.K; ++k)
     {
       const Mw<NL> t = mw::mul(mat_ld<NL>(bases, dbs, jj, k), mw::load<NL>(a, voff + k));
-      acc = mw::fma(mat_ld<NL>(bases, dbs, i, k), t, acc);
+      mw::acc_fma(sum, mat_ld<NL>(bases, dbs, i, k), t);
     }
+  Mw<NL> acc = mw::acc_result(sum);
   if(hi != lo)
     acc = mw::mul_2exp(acc, -1);
   if(addend_sign)
@@ -624,15 +641,15 @@ __global__ void __launch_bounds__(WG)
     {
       const int rs = bl.rows[b];
       const MatDesc dz = Z.d[2 * j + b], dbs = bases.d[2 * j + b];
-      Mw<NL> colsum = mw::zero<NL>();
+      Acc<NL> colsum = mw::acc_zero<NL>();
       for(int i = 0; i < rs; ++i)
         {
-          Mw<NL> zq = mw::zero<NL>();
+          Acc<NL> zq = mw::acc_zero<NL>();
           for(int l = 0; l < rs; ++l)
-            zq = mw::fma(mat_ld<NL>(Z, dz, rb * rs + i, cb * rs + l), mat_ld<NL>(bases, dbs, l, k), zq);
-          colsum = mw::fma(zq, mat_ld<NL>(bases, dbs, i, k), colsum);
+            mw::acc_fma(zq, mat_ld<NL>(Z, dz, rb * rs + i, cb * rs + l), mat_ld<NL>(bases, dbs, l, k));
+          mw::acc_fma(colsum, mw::acc_result(zq), mat_ld<NL>(bases, dbs, i, k));
         }
-      acc = mw::sub(acc, colsum);
+      acc = mw::sub(acc, mw::acc_result(colsum));
     }
   mw::store<NL>(dx, (size_t)bl.voff + p, acc);
 }
@@ -650,13 +667,16 @@ __global__ void __launch_bounds__(WG) k_gemv_t_partial(Batch MT, mw::CPtr v, mw:
   if(n >= N)
     return;
   const MatDesc dm = MT.d[j];
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> acc = mw::acc_zero<NL>();
   for(int p = 0; p < bl.P; ++p)
     {
       const Mw<NL> a = mat_ld<NL>(MT, dm, n, p);
-      acc = SQUARE ? mw::fma(a, a, acc) : mw::fma(a, mw::load<NL>(v, (size_t)bl.voff + p), acc);
+      if(SQUARE)
+        mw::acc_fma(acc, a, a);
+      else
+        mw::acc_fma(acc, a, mw::load<NL>(v, (size_t)bl.voff + p));
     }
-  mw::store<NL>(part, (size_t)j * N + n, acc);
+  mw::store<NL>(part, (size_t)j * N + n, mw::acc_result(acc));
 }
 // out[n] = (base ? base[n] : 0) + sign * sum_j part[j*N+n]
 template <int NL>
@@ -665,14 +685,12 @@ __global__ void __launch_bounds__(WG) k_sum_partials(mw::CPtr part, int J, int N
   const int n = blockIdx.x * WG + threadIdx.x;
   if(n >= N)
     return;
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> acc = mw::acc_zero<NL>();
   for(int j = 0; j < J; ++j)
-    acc = mw::add(acc, mw::load<NL>(part, (size_t)j * N + n));
-  if(sign < 0)
-    acc = mw::neg(acc);
+    mw::acc_add(acc, mw::load<NL>(part, (size_t)j * N + n), sign < 0 ? 1u : 0u);
   if(has_base)
-    acc = mw::add(mw::load<NL>(base, n), acc);
-  mw::store<NL>(out, n, acc);
+    mw::acc_add(acc, mw::load<NL>(base, n));
+  mw::store<NL>(out, n, mw::acc_result(acc));
 }
 // out_j[p] += sign * sum_n MT_j(n,p) v[n]: dx += P dy (solve_schur_complement_equation.
 // cxx:69-74) and d -= B y (compute_dual_residues_and_error.cxx:52-54).  A workgroup
@@ -686,14 +704,14 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
   const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
   const int p = blockIdx.x * 4 + sub;
   __shared__ Mw<NL> sm[WG];
-  Mw<NL> acc = mw::zero<NL>();
+  Acc<NL> sum = mw::acc_zero<NL>();
   if(p < bl.P)
     {
       const MatDesc dm = MT.d[j];
       for(int n = lane; n < N; n += 64)
-        acc = mw::fma(mat_ld<NL>(MT, dm, n, p), mw::load<NL>(v, n), acc);
+        mw::acc_fma(sum, mat_ld<NL>(MT, dm, n, p), mw::load<NL>(v, n));
     }
-  sm[threadIdx.x] = acc;
+  sm[threadIdx.x] = mw::acc_result(sum);
   __syncthreads();
   for(int s = 32; s > 0; s >>= 1)
     {
@@ -1029,13 +1047,13 @@ template <int NL> __global__ void __launch_bounds__(TRI_T) k_tridiag(Batch A, Ba
             mw::store<NL>(E.p, oe + i, mat_ld<NL>(A, d, i, l));
           continue;
         }
-      Mw<NL> part = mw::zero<NL>();
+      Acc<NL> hp = mw::acc_zero<NL>();
       for(int k = t; k <= l; k += TRI_T)
         {
           const Mw<NL> a = mat_ld<NL>(A, d, i, k);
-          part = mw::fma(a, a, part);
+          mw::acc_fma(hp, a, a);
         }
-      const Mw<NL> h0 = tri_reduce_sum<NL>(part, sm);
+      const Mw<NL> h0 = tri_reduce_sum<NL>(mw::acc_result(hp), sm);
       if(mw::is_zero(h0))
         {
           if(t == 0)
@@ -1064,14 +1082,14 @@ template <int NL> __global__ void __launch_bounds__(TRI_T) k_tridiag(Batch A, Ba
       for(int j0 = 0; j0 < w; j0 += teams)
         {
           const int j = j0 + t / G;
-          Mw<NL> acc = mw::zero<NL>();
+          Acc<NL> acc = mw::acc_zero<NL>();
           if(j < w && t / G < teams)
             for(int k = g; k < w; k += G)
               {
                 const Mw<NL> ajk = k <= j ? mat_ld<NL>(A, d, j, k) : mat_ld<NL>(A, d, k, j);
-                acc = mw::fma(ajk, mat_ld<NL>(A, d, i, k), acc);
+                mw::acc_fma(acc, ajk, mat_ld<NL>(A, d, i, k));
               }
-          sm[t] = acc;
+          sm[t] = mw::acc_result(acc);
           __syncthreads();
           if(g == 0 && j < w && t / G < teams)
             {
@@ -1097,10 +1115,11 @@ template <int NL> __global__ void __launch_bounds__(TRI_T) k_tridiag(Batch A, Ba
           while((j + 1) * (j + 2) / 2 <= idx)
             ++j;
           const int k = idx - j * (j + 1) / 2;
-          Mw<NL> v = mat_ld<NL>(A, d, j, k);
-          v = mw::fms(mat_ld<NL>(A, d, i, j), mw::load<NL>(E.p, oe + k), v);
-          v = mw::fms(mw::load<NL>(E.p, oe + j), mat_ld<NL>(A, d, i, k), v);
-          mat_st<NL>(A, d, j, k, v);
+          Acc<NL> v = mw::acc_zero<NL>();
+          mw::acc_add(v, mat_ld<NL>(A, d, j, k));
+          mw::acc_fms(v, mat_ld<NL>(A, d, i, j), mw::load<NL>(E.p, oe + k));
+          mw::acc_fms(v, mw::load<NL>(E.p, oe + j), mat_ld<NL>(A, d, i, k));
+          mat_st<NL>(A, d, j, k, mw::acc_result(v));
         }
       __syncthreads();
     }

@@ -350,47 +350,41 @@ template <int W> MW_HD void shl_bits(uint32_t (&x)[W], uint32_t c)
   x[0] = x[0] << c;
 }
 
-// bit i of the result = (w[I0+i] != 0), built as a balanced OR tree (log depth)
-template <int I0, int I1, int W> MW_HD uint32_t nonzero_mask(const uint32_t (&w)[W])
+// bit (i - BASE) of the result = (w[i] != 0) for i in [I0, I1], as a balanced OR tree
+template <int I0, int I1, int BASE, int W> MW_HD uint32_t nonzero_mask(const uint32_t (&w)[W])
 {
   if constexpr(I0 == I1)
-    return (w[I0] != 0 ? 1u : 0u) << I0;
+    return (w[I0] != 0 ? 1u : 0u) << (I0 - BASE);
   else
     {
       constexpr int MID = (I0 + I1) / 2;
-      return nonzero_mask<I0, MID, W>(w) | nonzero_mask<MID + 1, I1, W>(w);
+      return nonzero_mask<I0, MID, BASE, W>(w) | nonzero_mask<MID + 1, I1, BASE, W>(w);
     }
 }
-
-// Normalise a (NL+1)-limb magnitude w (value w/2^(32(NL+1)) * 2^e) into r.  The top
-// non-zero limb is located with a mask + clz (log depth), not a serial scan: this sits
-// on the dependent path of every subtraction.
-template <int NL> MW_HD Mw<NL> normalize_w(uint32_t (&w)[NL + 1], int32_t e, uint32_t neg)
+// index of the most significant non-zero limb, -1 if all are zero (log depth: this sits
+// on the dependent path of every subtraction)
+template <int W> MW_HD int top_nonzero(const uint32_t (&w)[W])
 {
-  static_assert(NL + 1 <= 64, "mask below is 64 bits wide");
-  uint32_t zl;
-  if constexpr(NL + 1 <= 32)
+  static_assert(W <= 64, "two 32-bit masks");
+  if constexpr(W <= 32)
     {
-      const uint32_t m = nonzero_mask<0, NL, NL + 1>(w);
-      if(m == 0)
-        return zero<NL>();
-      zl = (uint32_t)NL - (31u - clz32(m));
+      const uint32_t m = nonzero_mask<0, W - 1, 0, W>(w);
+      return m ? 31 - (int)clz32(m) : -1;
     }
   else
     {
-      uint32_t lo[32], hi[NL + 1 - 32];
-#pragma unroll
-      for(int i = 0; i < 32; ++i)
-        lo[i] = w[i];
-#pragma unroll
-      for(int i = 32; i <= NL; ++i)
-        hi[i - 32] = w[i];
-      const uint32_t mh = nonzero_mask<0, NL - 32, NL + 1 - 32>(hi), ml = nonzero_mask<0, 31, 32>(lo);
-      if((mh | ml) == 0)
-        return zero<NL>();
-      const uint32_t top = mh ? 32u + (31u - clz32(mh)) : (31u - clz32(ml));
-      zl = (uint32_t)NL - top;
+      const uint32_t mh = nonzero_mask<32, W - 1, 32, W>(w), ml = nonzero_mask<0, 31, 0, W>(w);
+      return mh ? 63 - (int)clz32(mh) : (ml ? 31 - (int)clz32(ml) : -1);
     }
+}
+
+// Normalise a (NL+1)-limb magnitude w (value w/2^(32(NL+1)) * 2^e) into r.
+template <int NL> MW_HD Mw<NL> normalize_w(uint32_t (&w)[NL + 1], int32_t e, uint32_t neg)
+{
+  const int top = top_nonzero<NL + 1>(w);
+  if(top < 0)
+    return zero<NL>();
+  const uint32_t zl = (uint32_t)(NL - top);
   shl_limbs<NL + 1>(w, zl);
   const uint32_t c = clz32(w[NL]);
   shl_bits<NL + 1>(w, c);
@@ -491,6 +485,165 @@ template <int NL> MW_HD Mw<NL> fma(const Mw<NL> &a, const Mw<NL> &b, const Mw<NL
 template <int NL> MW_HD Mw<NL> fms(const Mw<NL> &a, const Mw<NL> &b, const Mw<NL> &acc)
 {
   return add(acc, neg(mul(a, b)));
+}
+
+// ---- dot-product accumulator ------------------------------------------------
+// Sum of products without per-term normalisation: the running sum is a signed
+// (NL+2)-limb two's-complement integer W with a window exponent etop,
+//     value = W / 2^(32 (NL+1)) * 2^etop ,
+// i.e. NL+1 limbs of fraction below the largest term seen so far and one limb of
+// headroom (2^31 terms).  A term costs its product columns plus ONE aligned add
+// (shift network + carry chain); the expensive normalisation (leading-zero search,
+// left shift, magnitude ordering) happens once, in acc_result.  Terms are truncated
+// at 2^-(32(NL+1)) relative to the largest term, the rounding regime of a sequential
+// `acc += a*b` in mpf.
+template <int NL> struct Acc
+{
+  uint32_t w[NL + 2];
+  int32_t etop; // EZERO while empty
+};
+template <int NL> MW_HD Acc<NL> acc_zero()
+{
+  Acc<NL> a;
+#pragma unroll
+  for(int i = 0; i < NL + 2; ++i)
+    a.w[i] = 0;
+  a.etop = EZERO;
+  return a;
+}
+// arithmetic right shift of a two's-complement array by q limbs / c bits
+template <int W> MW_HD void sar_limbs(uint32_t (&x)[W], uint32_t q)
+{
+  const uint32_t fill = 0u - (x[W - 1] >> 31);
+#pragma unroll
+  for(int s = 1; s < W; s <<= 1)
+    {
+      const bool on = (q & (uint32_t)s) != 0;
+#pragma unroll
+      for(int i = 0; i < W; ++i)
+        {
+          const uint32_t from = (i + s < W) ? x[i + s < W ? i + s : 0] : fill;
+          x[i] = on ? from : x[i];
+        }
+    }
+}
+template <int W> MW_HD void sar_bits(uint32_t (&x)[W], uint32_t c)
+{
+  const uint32_t fill = 0u - (x[W - 1] >> 31);
+#pragma unroll
+  for(int i = 0; i < W - 1; ++i)
+    x[i] = funnel_r(x[i + 1], x[i], c);
+  x[W - 1] = funnel_r(fill, x[W - 1], c);
+}
+// acc += (-1)^negate * P / 2^(32(NL+1)) * 2^e with P an (NL+1)-limb magnitude
+template <int NL> MW_HD void acc_add_raw(Acc<NL> &acc, const uint32_t (&P)[NL + 1], int32_t e, uint32_t negative)
+{
+  if(e > acc.etop)
+    {
+      if(acc.etop != EZERO)
+        {
+          const uint32_t up = (uint32_t)(e - acc.etop);
+          if(up >= 32u * (NL + 2))
+            {
+              const uint32_t fill = 0u - (acc.w[NL + 1] >> 31);
+#pragma unroll
+              for(int i = 0; i < NL + 2; ++i)
+                acc.w[i] = fill; // -1 ulp or 0: what an arithmetic shift leaves
+            }
+          else
+            {
+              sar_limbs<NL + 2>(acc.w, up >> 5);
+              sar_bits<NL + 2>(acc.w, up & 31u);
+            }
+        }
+      acc.etop = e;
+    }
+  const uint32_t d = (uint32_t)(acc.etop - e);
+  if(d >= 32u * (NL + 1))
+    return;
+  uint32_t x[NL + 2];
+#pragma unroll
+  for(int i = 0; i <= NL; ++i)
+    x[i] = P[i];
+  x[NL + 1] = 0;
+  shr_limbs<NL + 2>(x, d >> 5);
+  shr_bits<NL + 2>(x, d & 31u);
+  const uint32_t mask = 0u - negative;
+  uint32_t carry = negative;
+#pragma unroll
+  for(int i = 0; i < NL + 2; ++i)
+    {
+      const uint64_t s = (uint64_t)acc.w[i] + (x[i] ^ mask) + carry;
+      acc.w[i] = (uint32_t)s;
+      carry = (uint32_t)(s >> 32);
+    }
+}
+// acc += a*b (negate: acc -= a*b)
+template <int NL> MW_HD void acc_fma(Acc<NL> &acc, const Mw<NL> &a, const Mw<NL> &b, uint32_t negate = 0)
+{
+  if(a.e == EZERO || b.e == EZERO)
+    return;
+  uint32_t r[NL + 1];
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+  if constexpr(NL >= 2)
+    {
+      mac_column<0, NL - 2, NL - 2>(lo, hi, a.m, b.m);
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+  MulColumns<NL, NL - 1>::run(a.m, b.m, lo, hi, r);
+  uint32_t P[NL + 1];
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    P[i] = r[i];
+  P[NL] = (uint32_t)lo; // product limbs NL-1 .. 2NL-1: fraction in [1/4, 1)
+  acc_add_raw<NL>(acc, P, a.e + b.e, a.neg ^ b.neg ^ (negate & 1u));
+}
+template <int NL> MW_HD void acc_fms(Acc<NL> &acc, const Mw<NL> &a, const Mw<NL> &b) { acc_fma(acc, a, b, 1u); }
+// acc += x (negate: acc -= x)
+template <int NL> MW_HD void acc_add(Acc<NL> &acc, const Mw<NL> &x, uint32_t negate = 0)
+{
+  if(x.e == EZERO)
+    return;
+  uint32_t P[NL + 1];
+  P[0] = 0;
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    P[i + 1] = x.m[i];
+  acc_add_raw<NL>(acc, P, x.e, x.neg ^ (negate & 1u));
+}
+// the accumulated sum as a normalised number (one truncation)
+template <int NL> MW_HD Mw<NL> acc_result(const Acc<NL> &acc)
+{
+  if(acc.etop == EZERO)
+    return zero<NL>();
+  uint32_t w[NL + 2];
+  const uint32_t negative = acc.w[NL + 1] >> 31;
+  const uint32_t mask = 0u - negative;
+  uint32_t carry = negative;
+#pragma unroll
+  for(int i = 0; i < NL + 2; ++i)
+    {
+      const uint64_t s = (uint64_t)(acc.w[i] ^ mask) + carry;
+      w[i] = (uint32_t)s;
+      carry = (uint32_t)(s >> 32);
+    }
+  // magnitude w / 2^(32(NL+2)) * 2^(etop+32): locate the top limb, shift, keep NL limbs
+  const int top = top_nonzero<NL + 2>(w);
+  if(top < 0)
+    return zero<NL>();
+  const uint32_t zl = (uint32_t)(NL + 1 - top);
+  shl_limbs<NL + 2>(w, zl);
+  const uint32_t c = clz32(w[NL + 1]);
+  shl_bits<NL + 2>(w, c);
+  Mw<NL> r;
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    r.m[i] = w[i + 2];
+  r.e = acc.etop + 32 - (int32_t)(32u * zl + c);
+  r.neg = negative;
+  return r;
 }
 
 // ---- reciprocal, division, square root ---------------------------------------
