@@ -101,13 +101,13 @@ def main():
 
         def fake_allreduce(ptr, count):
             tensor_from_pointer(ptr, count * 8, device).view(torch.int64).mul_(sim)
-            torch.cuda.synchronize(device)
+            torch.cuda.current_stream(device).synchronize()
             return 0
 
         def fake_allgather(send, recv, nbytes):
             r = tensor_from_pointer(recv, nbytes * sim, device).view(sim, nbytes)
             r.copy_(tensor_from_pointer(send, nbytes, device).unsqueeze(0).expand(sim, nbytes))
-            torch.cuda.synchronize(device)
+            torch.cuda.current_stream(device).synchronize()
             return 0
 
         solver.set_collectives(fake_allreduce, fake_allgather)

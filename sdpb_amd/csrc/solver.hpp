@@ -185,7 +185,7 @@ template <int NL> class Solver : public SolverBase
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
-  DevBuf<uint32_t> fx_, acc_, syrk_tiles_;
+  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_;
   DevBuf<double> eigF_;
   DevBuf<unsigned long long> acc64_;
   DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
@@ -206,6 +206,9 @@ template <int NL> class Solver : public SolverBase
   long iteration_ = 0;
   int terminate_reason_ = NotTerminated;
   Collectives coll_;
+  hipStream_t stream_q_ = nullptr; // Cholesky(Q) runs here, concurrently with stream_
+  hipEvent_t ev_q_ready_ = nullptr, ev_q_done_ = nullptr;
+  bool q_pending_ = false;
   hipEvent_t ev_syrk0_ = nullptr, ev_syrk1_ = nullptr;
   double syrk_kernel_ms_ = 0;
   long syrk_launches_ = 0;
@@ -229,6 +232,9 @@ public:
       throw SolverError(4, "sdpb_hip_create: need at least one block and N >= 1");
     owner_ = plan_block_owners(dims, num_points, N, world);
     HIP_CHECK(hipStreamCreate(&stream_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_q_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreate(&ev_q_ready_));
+    HIP_CHECK(hipEventCreate(&ev_q_done_));
     HIP_CHECK(hipEventCreate(&ev_syrk0_));
     HIP_CHECK(hipEventCreate(&ev_syrk1_));
     build_layout();
@@ -236,6 +242,12 @@ public:
   }
   ~Solver() override
   {
+    if(ev_q_ready_)
+      (void)hipEventDestroy(ev_q_ready_);
+    if(ev_q_done_)
+      (void)hipEventDestroy(ev_q_done_);
+    if(stream_q_)
+      (void)hipStreamDestroy(stream_q_);
     if(ev_syrk0_)
       (void)hipEventDestroy(ev_syrk0_);
     if(ev_syrk1_)
@@ -367,7 +379,11 @@ private:
     acc_.alloc(acc_stride_ * ACCW);
     syrk_tiles_.upload(syrk_tile_order(N_));
     if(world_ > 1)
-      acc64_.alloc(acc_stride_ * ACCW);
+      {
+        acc64_.alloc(acc_stride_ * ACCW);
+        xsend_.alloc((size_t)(NL + 2) * std::max(N_, 16));
+        xrecv_.alloc((size_t)(NL + 2) * std::max(N_, 16) * world_);
+      }
     flags_.alloc((size_t)2 * std::max(Jl_, 1) + 4);
   }
 
@@ -612,9 +628,15 @@ private:
     if(!coll_.allgather_bytes)
       throw SolverError(4, "world_size > 1 but no collectives were registered (sdpb_hip_set_collectives)");
     const size_t words = (size_t)(NL + 2) * v.size();
-    DevBuf<uint32_t> send, recv;
-    send.alloc(words);
-    recv.alloc(words * world_);
+    // persistent exchange buffers: hipMalloc/hipFree would synchronise the whole device,
+    // including the stream that factors Q concurrently
+    if(xsend_.n < words || xrecv_.n < words * world_)
+      {
+        HIP_CHECK(hipDeviceSynchronize());
+        xsend_.alloc(words);
+        xrecv_.alloc(words * world_);
+      }
+    DevBuf<uint32_t> &send = xsend_, &recv = xrecv_;
     std::vector<uint32_t> h(words);
     for(size_t i = 0; i < v.size(); ++i)
       {
@@ -626,7 +648,8 @@ private:
     HIP_CHECK(hipMemcpy(send.p, h.data(), words * 4, hipMemcpyHostToDevice));
     if(coll_.allgather_bytes(coll_.user, send.p, recv.p, words * 4) != 0)
       throw HipError(3, "allgather callback failed");
-    std::vector<uint32_t> g = recv.download();
+    std::vector<uint32_t> g(words * world_);
+    HIP_CHECK(hipMemcpy(g.data(), recv.p, g.size() * 4, hipMemcpyDeviceToHost));
     std::vector<M> out(v.size() * world_);
     for(size_t i = 0; i < out.size(); ++i)
       {
@@ -701,20 +724,22 @@ private:
   void clear_flags() { HIP_CHECK(hipMemsetAsync(flags_.p, 0, flags_.n * sizeof(int), stream_)); }
 
   // A = L L^T in place for a batch (lower factor; Li receives the inverted diagonal blocks)
-  void blocked_cholesky(const Batch &A, const Batch &invd, const Batch &Li, int max_n, int *fail)
+  void blocked_cholesky(const Batch &A, const Batch &invd, const Batch &Li, int max_n, int *fail, hipStream_t st = nullptr)
   {
+    if(!st)
+      st = stream_;
     const int panels = cdiv(max_n, PB);
     for(int p = 0; p < panels; ++p)
       {
-        launch(k_chol_inv_lds<NL>, dim3(A.count), dim3(CI_T), stream_, A, invd, Li, p, fail);
+        launch(k_chol_inv_lds<NL>, dim3(A.count), dim3(CI_T), st, A, invd, Li, p, fail);
         const int below = max_n - PB * (p + 1), above = PB * p;
         const int rows = std::max(below, above);
         if(rows > 0)
-          launch(k_chol_panel_solve<NL>, dim3(cdiv(rows, TR), A.count), dim3(WG), stream_, A, Li, p);
+          launch(k_chol_panel_solve<NL>, dim3(cdiv(rows, TR), A.count), dim3(WG), st, A, Li, p);
         if(below > 0)
           {
             const unsigned tiles = cdiv(below, 16);
-            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), stream_, A, p);
+            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), st, A, p);
           }
       }
   }
@@ -947,10 +972,7 @@ private:
       launch(k_restore_Q<NL, FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_,
              norms_.cptr(), Q_.ptr(), qflags + 1);
     }
-    {
-      Timer t(this, "initializeSchurComplementSolver.Cholesky_Q");
-      cholesky_Q();
-    }
+    cholesky_Q_async();
   }
   // exact cross-GPU sum of the fixed-point Q' images
   void reduce_Q_accumulators()
@@ -966,15 +988,30 @@ private:
            acc_stride_, ACCW, acc_.p);
   }
   // El::Cholesky(UPPER,Q) (initialize_schur_complement_solver.cxx:95-103), stored here
-  // as the lower factor L = U^T; right-looking blocked: diagonal block in one
-  // workgroup, panel rows one lane each, trailing update over the whole chip.
-  void cholesky_Q()
+  // as the lower factor L = U^T (blocked, see kernels.hpp).  The factorisation is a long
+  // dependent chain that occupies a handful of CUs, so it runs on its own stream while
+  // the main stream goes on with -XY, mu, R-error and the part of the predictor that does
+  // not need Q (R, Z, the Schur right-hand side, L^{-1} dx, P^T dx); join_cholesky_Q()
+  // joins before the first Q solve.
+  void cholesky_Q_async()
   {
     int *qflags = flags_.p + 2 * std::max(Jl_, 1);
-    blocked_cholesky(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags);
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
+    HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
+    blocked_cholesky(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags, stream_q_);
+    HIP_CHECK(hipEventRecord(ev_q_done_, stream_q_));
+    q_pending_ = true;
+  }
+  void join_cholesky_Q()
+  {
+    if(!q_pending_)
+      return;
+    q_pending_ = false;
+    Timer t(this, "initializeSchurComplementSolver.Cholesky_Q(join)");
+    HIP_CHECK(hipStreamWaitEvent(stream_, ev_q_done_, 0));
+    HIP_CHECK(hipEventSynchronize(ev_q_done_));
     int f[4];
-    HIP_CHECK(hipMemcpy(f, qflags, sizeof f, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(f, flags_.p + 2 * std::max(Jl_, 1), sizeof f, hipMemcpyDeviceToHost));
     if(f[1])
       throw SolverError(1, "Normalized Q should have ones on diagonal. For i = " + std::to_string(f[1] - 1));
     if(f[0])
@@ -992,6 +1029,7 @@ private:
       Timer t(this, "searchDirection.solve.dy_PTdx");
       gemv_t_all<false>(PT_, dx_, &rp_, -1, dy_); // dy = p - sum_j P_j^T dx_j
     }
+    join_cholesky_Q();
     {
       Timer t(this, "searchDirection.solve.dy_Qinv");
       // El::cholesky::SolveAfter with the blocked factor: forward (dy -> qtmpv_), then
@@ -1188,7 +1226,10 @@ private:
       mu_ = mw::div(mw::neg(tr), mw::from_u32<NL>((uint32_t)total_psd_rows_));
     }
     if(mw::gt(mu_, max_complementarity_))
-      return true;
+      {
+        join_cholesky_Q();
+        return true;
+      }
     {
       // compute_R_error.hxx:9-29 : max |(-XY) + mu I|
       Timer t(this, "R_error");
@@ -1342,6 +1383,7 @@ public:
   std::string get_array(const std::string &which, int j, int parity) override
   {
     const ArrayRef r = locate(which, j, parity);
+    join_cholesky_Q();
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<M> v = download<NL>(*r.a, r.off, r.count);
     std::string out;

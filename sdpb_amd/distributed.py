@@ -36,7 +36,9 @@ def make_collectives(device: torch.device, group=None):
             t = tensor_from_pointer(ptr, count * 8, device).view(torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # wrapping int64 sum == uint64 sum
             if device.type == "cuda":
-                torch.cuda.synchronize(device)
+                # only the stream the collective was ordered on: the library keeps an independent
+                # stream busy (Cholesky(Q)) that a device-wide synchronize would wait for
+                torch.cuda.current_stream(device).synchronize()
             return 0
         except Exception as e:  # pragma: no cover - surfaced through the C ABI as code 3
             print("allreduce callback failed:", e, flush=True)
@@ -49,7 +51,7 @@ def make_collectives(device: torch.device, group=None):
             dist.all_gather_into_tensor(r, s, group=group) if device.type == "cuda" else \
                 dist.all_gather(list(r.view(world, nbytes).unbind(0)), s, group=group)
             if device.type == "cuda":
-                torch.cuda.synchronize(device)
+                torch.cuda.current_stream(device).synchronize()
             return 0
         except Exception as e:  # pragma: no cover
             print("allgather callback failed:", e, flush=True)

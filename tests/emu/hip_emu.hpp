@@ -136,6 +136,16 @@ inline hipError_t hipStreamCreate(hipStream_t *s)
   return hipSuccess;
 }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+enum
+{
+  hipStreamDefault = 0,
+  hipStreamNonBlocking = 1
+};
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
+{
+  *s = nullptr;
+  return hipSuccess;
+}
 inline hipError_t hipEventCreate(hipEvent_t *e)
 {
   *e = new hipEmuEvent;
@@ -152,6 +162,7 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr)
   return hipSuccess;
 }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
