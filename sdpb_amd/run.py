@@ -1,0 +1,191 @@
+"""`python -m sdpb_amd.run -s <sdpDir> --precision <p> -o <outDir> [sdpb solver options]`
+
+The driver that sits where `sdpb`'s `solve()` sits (src/sdpb/solve.cxx:23-106): reads the unchanged
+SDP directory format, runs the device-resident interior-point loop through the C ABI and writes
+sdpb's own result files:
+
+  out/out.txt            terminateReason, primalObjective, ... (src/sdpb/save_solution.cxx:29-39)
+  out/iterations.json    one record per iteration (print_iteration.cxx:77-108)
+  out/y.txt, out/z.txt   (save_solution.cxx:41-107; z needs normalization.json)
+  out/x_<j>.txt, X_matrix_<q>.txt, Y_matrix_<q>.txt  (save_solution.cxx:123-149, write_distmatrix.hxx)
+
+Option names and defaults are sdpb's (Solver_Parameters.cxx:10-157, SDPB_Parameters.cxx:21-82).
+Only I/O and the loop live here; every number is computed on the GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+from typing import List, Optional
+
+from .sdp_io import read_sdp
+from .solver import ITERATION_KEYS, PARAM_NAMES, SDPSolver
+
+HEADER = ("\n          time    mu     P-obj       D-obj      gap         P-err       p-err       D-err"
+          "      P-step   D-step   beta\n" + "-" * 117)
+
+
+def _options(argv: Optional[List[str]] = None):
+    ap = argparse.ArgumentParser(prog="sdpb_amd.run", description=__doc__.split("\n\n")[0])
+    ap.add_argument("-s", "--sdpDir", required=True)
+    ap.add_argument("-o", "--outDir", default=None, help="default: <sdpDir>_out")
+    ap.add_argument("--precision", type=int, default=400)
+    ap.add_argument("--maxIterations", type=int, default=500)
+    ap.add_argument("--maxRuntime", type=float, default=float("inf"))
+    for name, default in (("dualityGapThreshold", "1e-30"), ("primalErrorThreshold", "1e-30"),
+                          ("dualErrorThreshold", "1e-30"), ("initialMatrixScalePrimal", "1e20"),
+                          ("initialMatrixScaleDual", "1e20"), ("feasibleCenteringParameter", "0.1"),
+                          ("infeasibleCenteringParameter", "0.3"), ("stepLengthReduction", "0.7"),
+                          ("maxComplementarity", "1e100"), ("minPrimalStep", "0"), ("minDualStep", "0")):
+        ap.add_argument("--" + name, default=default)
+    for flag in ("findPrimalFeasible", "findDualFeasible", "detectPrimalFeasibleJump", "detectDualFeasibleJump"):
+        ap.add_argument("--" + flag, action="store_true")
+    ap.add_argument("--writeSolution", default="x,y", help="comma separated subset of x,y,X,Y,z")
+    ap.add_argument("--verbosity", type=int, default=1)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--noFinalCheckpoint", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--lib", default=None, help="path of the C-ABI library (tests: the CPU emulation build)")
+    return ap.parse_args(argv)
+
+
+def parse_option_like_sdpb(text: str) -> str:
+    """sdpb parses its numeric options before --precision is applied, i.e. with GMP's start-up
+    64-bit mpf precision (visible in the golden traces: beta = 0.2999...98725e-58 for
+    --infeasibleCenteringParameter 0.3).  mpf_set_str keeps prec+1 = 3 limbs of 64 bits,
+    limb-aligned and truncated toward zero; this returns the exact decimal expansion of that
+    number so the device solver starts from the same parameter VALUES as the reference.
+    (For |decimal exponent| > 57 GMP also truncates the power of ten it multiplies by; the
+    result then differs from this one by < 2^-128 relative — thresholds only.)"""
+    from fractions import Fraction
+    t = text.strip().lower()
+    mant, _, e = t.partition("e")
+    e10 = int(e) if e else 0
+    neg = mant.startswith("-")
+    mant = mant.lstrip("+-")
+    ip, _, fp = mant.partition(".")
+    v = Fraction(int((ip + fp) or "0")) * Fraction(10) ** (e10 - len(fp))
+    if v == 0:
+        return "0"
+    num, den = v.numerator, v.denominator
+    bl = num.bit_length() - den.bit_length()
+    if bl >= 0:
+        fl = bl if num >= (den << bl) else bl - 1
+    else:
+        fl = bl if (num << -bl) >= den else bl - 1
+    shift = 64 * (3 - (fl // 64 + 1))          # value * 2^shift fills exactly three limbs
+    q = (num << shift) // den if shift >= 0 else (num // (den << -shift)) << -shift
+    shift = max(shift, 0)
+    digits = str(q * 5 ** shift).rjust(shift + 1, "0")   # q / 2^shift = q 5^shift / 10^shift
+    out = digits[:-shift] + "." + digits[-shift:] if shift else digits
+    return ("-" if neg else "") + out
+
+
+def _digits(precision: int) -> int:
+    # set_stream_precision: ceil(precision * log10(2)) + 1 significant digits
+    return int(math.ceil(precision * math.log10(2.0))) + 1
+
+
+def _write_vector(path: str, values: List[str]):
+    with open(path, "w") as f:
+        f.write(f"{len(values)} 1\n" + "\n".join(values) + "\n\n")
+
+
+def _write_matrix(path: str, colmajor: List[str], n: int):
+    with open(path, "w") as f:
+        f.write(f"{n} {n}\n")
+        for i in range(n):
+            f.write(" ".join(colmajor[i + j * n] for j in range(n)) + "\n")
+        f.write("\n")
+
+
+def _z_from_y(y: List[str], normalization: List[str], precision: int) -> List[str]:
+    """save_solution.cxx:67-107: insert the component fixed by n.z = 1 at max |n_i|."""
+    import mpmath
+    with mpmath.workprec(precision + 64):
+        n = [mpmath.mpf(v) for v in normalization]
+        yv = [mpmath.mpf(v) for v in y]
+        k = max(range(len(n)), key=lambda i: abs(n[i]))
+        z = yv[:k] + [mpmath.mpf(0)] + yv[k:]
+        nz = mpmath.fsum(a * b for a, b in zip(n, z))
+        z[k] = (1 - nz) / n[k]
+        return [mpmath.nstr(v, _digits(precision), strip_zeros=False) for v in z]
+
+
+def solve(argv: Optional[List[str]] = None) -> str:
+    o = _options(argv)
+    out_dir = o.outDir or (o.sdpDir.rstrip("/") + "_out")
+    os.makedirs(out_dir, exist_ok=True)
+    sdp = read_sdp(o.sdpDir)
+    params = {k: parse_option_like_sdpb(getattr(o, k)) for k in PARAM_NAMES}
+    params.update(maxIterations=o.maxIterations, findPrimalFeasible=int(o.findPrimalFeasible),
+                  findDualFeasible=int(o.findDualFeasible),
+                  detectPrimalFeasibleJump=int(o.detectPrimalFeasibleJump),
+                  detectDualFeasibleJump=int(o.detectDualFeasibleJump))
+    start = time.time()
+    solver = SDPSolver(sdp, o.precision, params, device=o.device, lib_path=o.lib)
+    if o.verbosity >= 1:
+        print(f"Initialize SDP solver\n\tprimal dimension: {sdp.P_total}\n\tdual dimension: {sdp.N}"
+              f"\n\tSDP blocks: {sdp.J}")
+        print(HEADER)
+    it_path = os.path.join(out_dir, "iterations.json")
+    reason = None
+    with open(it_path, "w") as itf:
+        itf.write("[")
+        while reason is None:
+            t_it = time.time()
+            if solver.iterate():
+                reason = solver.terminate_reason
+                break
+            rec = solver.scalars()
+            now = time.time()
+            itf.write(("," if solver.iteration > 1 else "") + "\n{ \"iteration\":%d, \"total_time\": %.3f, "
+                      "\"iter_time\": %.3f" % (solver.iteration, now - start, now - t_it)
+                      + "".join(f", \"{k}\": \"{rec[k]}\"" for k in ITERATION_KEYS)
+                      + f", \"block_name\": \"{rec['block_name']}\" }}")
+            if o.verbosity >= 1:
+                f = lambda k: float(rec[k])  # noqa: E731
+                print(f"{solver.iteration:<4d}  {int(now - start):>8d} {f('mu'):<8.2g} {f('P-obj'):<+11.3g} "
+                      f"{f('D-obj'):<+11.3g} {f('gap'):<10.3g} {f('P-err'):<+11.3g} {f('p-err'):<+11.3g} "
+                      f"{f('D-err'):<+11.3g} {f('P-step'):<8.3g} {f('D-step'):<8.3g} {f('beta'):<4.3g}", flush=True)
+            if now - start >= o.maxRuntime:
+                reason = "maxRuntime exceeded"
+        itf.write("\n]")
+    runtime = int(time.time() - start)
+    out = solver.out_txt()
+    out["terminateReason"] = reason
+    with open(os.path.join(out_dir, "out.txt"), "w") as f:
+        f.write(f"terminateReason = \"{reason}\";\n"
+                f"primalObjective = {out['primalObjective']};\ndualObjective   = {out['dualObjective']};\n"
+                f"dualityGap      = {out['dualityGap']};\nprimalError     = {out['primalError']};\n"
+                f"dualError       = {out['dualError']};\nSolver runtime  = {runtime};\n")
+    what = set(w for w in o.writeSolution.split(",") if w)
+    y = solver.array("y")
+    if "y" in what:
+        _write_vector(os.path.join(out_dir, "y.txt"), y)
+    if "z" in what and sdp.normalization:
+        _write_vector(os.path.join(out_dir, "z.txt"), _z_from_y(y, sdp.normalization, o.precision))
+    for j, blk in enumerate(sdp.blocks):
+        if "x" in what:
+            _write_vector(os.path.join(out_dir, f"x_{j}.txt"), solver.array("x", j))
+        for parity, n in enumerate(blk.psd_sizes):
+            if n == 0:
+                continue
+            for name in ("X", "Y"):
+                if name in what:
+                    _write_matrix(os.path.join(out_dir, f"{name}_matrix_{2 * j + parity}.txt"),
+                                  solver.array(name, j, parity), n)
+    if o.verbosity >= 1:
+        print(f"-----{reason}-----\n")
+        for k in ("primalObjective", "dualObjective", "dualityGap", "primalError", "dualError"):
+            print(f"{k:16s}= {out[k]}")
+        print(f"Saving solution to      : {out_dir}")
+    solver.close()
+    return reason
+
+
+if __name__ == "__main__":
+    solve()
+    sys.exit(0)

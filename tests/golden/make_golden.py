@@ -64,7 +64,8 @@ def main():
                     "control.json", "objectives.json", "normalization.json"):
                 shutil.copy(os.path.join(src, "sdp", f), os.path.join(dst, "sdp", f))
         shutil.copy(os.path.join(src, "out", itfile), os.path.join(dst, "iterations.json"))
-        for f in ("out.txt", "y.txt"):
+        xs = sorted(f for f in os.listdir(os.path.join(src, "out")) if f.startswith("x_") and f.endswith(".txt"))
+        for f in ["out.txt", "y.txt"] + xs:
             shutil.copy(os.path.join(src, "out", f), os.path.join(dst, f))
         meta[name] = {"precision": prec, "params": params, "source": source,
                       "reference_dir": "test/data/end-to-end_tests/" + sub}

