@@ -736,10 +736,91 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
 // accumulated exactly in a (2FX+2)-limb two's-complement integer — no alignment,
 // no normalisation inside the hot loop, just v_mad_u64_u32 + carry.
 // ---------------------------------------------------------------------------
-// fx[idx] = trunc(PT[idx] * inv_norm[idx % N] * 2^(32 FX));  plane 0 of fx = sign.
+// The fixed-point image is BIASED so that every operand of the hot loop is a
+// non-negative integer and whole columns of products can be accumulated across rows
+// without a sign decision per product:
+//   v  = trunc(P' 2^FB) (signed),  FB = 32 FX - 3 fractional bits,
+//   a' = v + C,  C = 2^FB,  0 < a' < 2^(32FX-2),
+//   a' = hi B + lo,  B = 2^(32M-1),  M = FX/2,  lo, hi < B,  s = lo + hi < 2^(32M).
+// Planes of fx (limb-major, 3M planes): lo[0..M), hi[0..M), s[0..M).
+//   sum_r a'_ri a'_rj = HH B^2 + (SS - LL - HH) B + LL        (one Karatsuba level over
+//   LL = sum lo lo,  HH = sum hi hi,  SS = sum s s             the SUMS: 3/4 of the MACs)
+//   sum_r v_ri v_rj   = G(i,j) - C (S_i + S_j) + n C^2,  S_i = sum_r a'_ri  (k_fx_colsum)
+// Everything is integer and exact; three bits of the 32 FX-bit image pay for the bias
+// and for the carry-free s = lo + hi.
+template <int FX> constexpr int fx_planes() { return 3 * (FX / 2); }
+template <int FX> constexpr int fx_frac_bits() { return 32 * FX - 3; }
+
+// add x << SH (x an A-limb unsigned integer) into the W-limb integer w; negate: subtract
+template <int W, int A> MW_HD void add_shifted(uint32_t (&w)[W], const uint32_t (&x)[A], int sh, bool negate)
+{
+  const int q = sh >> 5, r = sh & 31;
+  uint64_t cy = negate ? 1u : 0u;
+  const uint32_t mask = negate ? 0xffffffffu : 0u;
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    {
+      const int i0 = k - q;
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for(int t = 0; t < A; ++t)
+        {
+          lo = (t == i0 - 1) ? x[t] : lo;
+          hi = (t == i0) ? x[t] : hi;
+        }
+      const uint32_t limb = r ? ((hi << r) | (lo >> (32 - r))) : hi;
+      const uint64_t s = (uint64_t)w[k] + (uint64_t)(limb ^ mask) + cy;
+      w[k] = (uint32_t)s;
+      cy = s >> 32;
+    }
+}
+
+// write the 3M planes of one element from sign + FX-limb magnitude (|v| < 2^FB)
+template <int FX> MW_HD void fx_store(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
+{
+  constexpr int M = FX / 2;
+  static_assert(FX % 2 == 0 && FX >= 4, "FX = NL - 2 is even");
+  // a' = C +/- |v|, C = bit 29 of the top limb
+  uint32_t a[FX];
+  uint64_t borrow = 0;
+#pragma unroll
+  for(int i = 0; i < FX; ++i)
+    {
+      const uint32_t c = (i == FX - 1) ? (1u << 29) : 0u;
+      if(negative)
+        {
+          const uint64_t d = (uint64_t)c - (uint64_t)mag[i] - borrow;
+          a[i] = (uint32_t)d;
+          borrow = (d >> 63) & 1u;
+        }
+      else
+        a[i] = mag[i] | c;
+    }
+  uint32_t lo[M], hi[M];
+#pragma unroll
+  for(int i = 0; i < M; ++i)
+    {
+      lo[i] = (i == M - 1) ? (a[i] & 0x7fffffffu) : a[i];
+      const uint32_t up = (M + i < FX) ? a[M + i < FX ? M + i : 0] : 0u;
+      hi[i] = (a[M - 1 + i] >> 31) | (up << 1);
+    }
+  uint64_t cy = 0;
+#pragma unroll
+  for(int i = 0; i < M; ++i)
+    {
+      const uint64_t s = (uint64_t)lo[i] + hi[i] + cy;
+      cy = s >> 32;
+      fx[(size_t)i * fx_stride + idx] = lo[i];
+      fx[(size_t)(M + i) * fx_stride + idx] = hi[i];
+      fx[(size_t)(2 * M + i) * fx_stride + idx] = (uint32_t)s;
+    }
+}
+
+// fx[idx] = image of trunc(PT[idx] * inv_norm[idx % N] * 2^FB)
 template <int NL, int FX>
 __global__ void __launch_bounds__(WG) k_normalize_fx(mw::CPtr PT, size_t count, int N, mw::CPtr inv_norm, uint32_t *fx, size_t fx_stride)
 {
+  constexpr int FB = fx_frac_bits<FX>();
   for(size_t idx = (size_t)blockIdx.x * WG + threadIdx.x; idx < count; idx += (size_t)gridDim.x * WG)
     {
       const Mw<NL> t = mw::mul(mw::load<NL>(PT, idx), mw::load<NL>(inv_norm, idx % N));
@@ -756,10 +837,10 @@ __global__ void __launch_bounds__(WG) k_normalize_fx(mw::CPtr PT, size_t count, 
 #pragma unroll
           for(int i = 0; i < NL; ++i)
             w[i] = t.m[i];
-          // integer = M * 2^(e + 32FX - 32NL): shift right by s
-          const int s = 32 * NL - 32 * FX - t.e;
+          // integer = M * 2^(e + FB - 32NL): shift right by s
+          const int s = 32 * NL - FB - t.e;
           if(t.e >= 1)
-            sat = true; // |t| >= 1 (only t == 1 up to rounding): clamp to 2^(32FX)-1
+            sat = true; // |t| >= 1 (only t == 1 up to rounding): clamp to 2^FB - 1
           else if(s >= 32 * NL)
             {
 #pragma unroll
@@ -772,16 +853,128 @@ __global__ void __launch_bounds__(WG) k_normalize_fx(mw::CPtr PT, size_t count, 
               mw::shr_bits<NL>(w, (uint32_t)s & 31u);
             }
         }
-      bool nz = false;
+      uint32_t v[FX];
 #pragma unroll
       for(int i = 0; i < FX; ++i)
-        {
-          const uint32_t v = sat ? 0xffffffffu : w[i];
-          nz = nz || v != 0;
-          fx[(size_t)(i + 1) * fx_stride + idx] = v;
-        }
-      fx[idx] = (nz && t.neg) ? 1u : 0u;
+        v[i] = sat ? ((i == FX - 1) ? 0x1fffffffu : 0xffffffffu) : w[i];
+      fx_store<FX>(v, t.neg != 0, fx, fx_stride, idx);
     }
+}
+
+// the same image from staged planes: plane 0 = sign, planes 1..FX = |v| (sdpb_hip_op_int_syrk);
+// in and out are distinct buffers
+template <int FX> __global__ void __launch_bounds__(WG) k_fx_from_int(const uint32_t *in, size_t count, uint32_t *fx, size_t fx_stride)
+{
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= count)
+    return;
+  uint32_t v[FX];
+#pragma unroll
+  for(int i = 0; i < FX; ++i)
+    v[i] = in[(size_t)(i + 1) * count + idx];
+  fx_store<FX>(v, in[idx] != 0, fx, fx_stride, idx);
+}
+
+// Column sums S_n = sum_r a'_rn, as (2FX+2)-limb integers stored behind the N x N
+// outputs of the accumulator array (element N*N + n of every plane), so that they ride
+// through the same cross-GPU reduction as G.  Stage 1: workgroup (x, y) sums row slice y
+// of 64 columns (4 row phases per column, meeting in LDS) into partial[y]; stage 2 adds
+// the slices.  partial element (slice, k, n) at (slice * 2(M+2) + k) * N + n; k < M+2:
+// sum of lo, else sum of hi.
+template <int FX>
+__global__ void __launch_bounds__(WG) k_fx_colsum(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, unsigned rows_per_slice, uint32_t *partial)
+{
+  constexpr int M = FX / 2, A = M + 2;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), phase = threadIdx.x >> 6;
+  const unsigned r_begin = blockIdx.y * rows_per_slice, r_end = (r_begin + rows_per_slice < nrows) ? r_begin + rows_per_slice : nrows;
+  uint32_t sl[A], sh[A];
+#pragma unroll
+  for(int k = 0; k < A; ++k)
+    sl[k] = sh[k] = 0;
+  if(col < N)
+    for(unsigned r = r_begin + phase; r < r_end; r += 4)
+      {
+        const size_t e = (size_t)r * N + col;
+        uint64_t cl = 0, ch = 0;
+#pragma unroll
+        for(int k = 0; k < A; ++k)
+          {
+            const uint64_t l = (uint64_t)sl[k] + (k < M ? fx[(size_t)(k < M ? k : 0) * fx_stride + e] : 0u) + cl;
+            const uint64_t h = (uint64_t)sh[k] + (k < M ? fx[(size_t)(M + (k < M ? k : 0)) * fx_stride + e] : 0u) + ch;
+            sl[k] = (uint32_t)l;
+            cl = l >> 32;
+            sh[k] = (uint32_t)h;
+            ch = h >> 32;
+          }
+      }
+  __shared__ uint32_t sm[3 * 2 * A * 64];
+  if(phase > 0)
+    {
+#pragma unroll
+      for(int k = 0; k < A; ++k)
+        {
+          sm[((phase - 1) * 2 * A + k) * 64 + (threadIdx.x & 63)] = sl[k];
+          sm[((phase - 1) * 2 * A + A + k) * 64 + (threadIdx.x & 63)] = sh[k];
+        }
+    }
+  __syncthreads();
+  if(phase == 0 && col < N)
+    {
+      for(int p = 0; p < 3; ++p)
+        {
+          uint64_t cl = 0, ch = 0;
+#pragma unroll
+          for(int k = 0; k < A; ++k)
+            {
+              const uint64_t l = (uint64_t)sl[k] + sm[(p * 2 * A + k) * 64 + threadIdx.x] + cl;
+              const uint64_t h = (uint64_t)sh[k] + sm[(p * 2 * A + A + k) * 64 + threadIdx.x] + ch;
+              sl[k] = (uint32_t)l;
+              cl = l >> 32;
+              sh[k] = (uint32_t)h;
+              ch = h >> 32;
+            }
+        }
+#pragma unroll
+      for(int k = 0; k < A; ++k)
+        {
+          partial[((size_t)blockIdx.y * 2 * A + k) * N + col] = sl[k];
+          partial[((size_t)blockIdx.y * 2 * A + A + k) * N + col] = sh[k];
+        }
+    }
+}
+template <int FX>
+__global__ void __launch_bounds__(WG) k_fx_colsum_final(const uint32_t *partial, int nslices, int N, uint32_t *acc, size_t acc_stride)
+{
+  constexpr int M = FX / 2, A = M + 2, W = 2 * FX + 2;
+  const int col = blockIdx.x * WG + threadIdx.x;
+  if(col >= N)
+    return;
+  uint32_t sl[A], sh[A];
+#pragma unroll
+  for(int k = 0; k < A; ++k)
+    sl[k] = sh[k] = 0;
+  for(int s = 0; s < nslices; ++s)
+    {
+      uint64_t cl = 0, ch = 0;
+#pragma unroll
+      for(int k = 0; k < A; ++k)
+        {
+          const uint64_t l = (uint64_t)sl[k] + partial[((size_t)s * 2 * A + k) * N + col] + cl;
+          const uint64_t h = (uint64_t)sh[k] + partial[((size_t)s * 2 * A + A + k) * N + col] + ch;
+          sl[k] = (uint32_t)l;
+          cl = l >> 32;
+          sh[k] = (uint32_t)h;
+          ch = h >> 32;
+        }
+    }
+  uint32_t w[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    w[k] = k < A ? sl[k < A ? k : 0] : 0u;
+  add_shifted<W, A>(w, sh, 32 * M - 1, false);
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    acc[(size_t)k * acc_stride + (size_t)N * N + col] = w[k];
 }
 
 // Lower-triangle 16x16 tiles of an N x N output, enumerated super-block by super-block
@@ -802,37 +995,96 @@ inline std::vector<uint32_t> syrk_tile_order(int N)
   return out;
 }
 
-// columns K .. 2FX-2 of one signed product folded into the accumulator (see k_syrk_fx)
-template <int FX, int K> struct SyrkColumns
+// all 2M-1 columns of one row's M x M limb product into column accumulators that
+// persist across rows: c[K] (64 bits) + h[K] 2^64 collects column K
+template <int M, int K> struct SyrkColumns
 {
-  static MW_HD void run(const uint32_t (&a)[FX], const uint32_t (&b)[FX], uint64_t &lo, uint32_t &hi, uint32_t (&acc)[2 * FX + 2],
-                        uint32_t mask, uint32_t &carry)
+  static MW_HD void run(const uint32_t (&a)[M], const uint32_t (&b)[M], uint64_t (&c)[2 * M - 1], uint32_t (&h)[2 * M - 1])
   {
-    constexpr int I0 = K - (FX - 1) > 0 ? K - (FX - 1) : 0, I1 = K < FX - 1 ? K : FX - 1;
-    mw::mac_column<I0, I1, K>(lo, hi, a, b);
-    const uint32_t limb = (uint32_t)lo ^ mask;
-    lo = (lo >> 32) | ((uint64_t)hi << 32);
-    hi = 0;
-    const uint64_t s = (uint64_t)acc[K] + limb + carry;
-    acc[K] = (uint32_t)s;
-    carry = (uint32_t)(s >> 32);
-    if constexpr(K < 2 * FX - 2)
-      SyrkColumns<FX, K + 1>::run(a, b, lo, hi, acc, mask, carry);
+    constexpr int I0 = K - (M - 1) > 0 ? K - (M - 1) : 0, I1 = K < M - 1 ? K : M - 1;
+    mw::mac_column<I0, I1, K>(c[K], h[K], a, b);
+    if constexpr(K < 2 * M - 2)
+      SyrkColumns<M, K + 1>::run(a, b, c, h);
   }
 };
+// acc += sum_K (c[K] + h[K] 2^64) 2^(32K): three carry chains (low words, high words, overflows)
+template <int M> MW_HD void syrk_fold(uint32_t (&acc)[2 * M + 2], const uint64_t (&c)[2 * M - 1], const uint32_t (&h)[2 * M - 1])
+{
+  constexpr int A = 2 * M + 2, NC = 2 * M - 1;
+  const uint32_t zero = 0;
+  mw::Carry cy;
+  {
+    const uint32_t x = (uint32_t)c[0];
+    MW_ADD_CO(acc[0], x, cy);
+  }
+#pragma unroll
+  for(int k = 1; k < A; ++k)
+    {
+      const uint32_t x = k < NC ? (uint32_t)c[k < NC ? k : 0] : zero;
+      MW_ADDC(acc[k], x, cy);
+    }
+  {
+    const uint32_t x = (uint32_t)(c[0] >> 32);
+    MW_ADD_CO(acc[1], x, cy);
+  }
+#pragma unroll
+  for(int k = 2; k < A; ++k)
+    {
+      const uint32_t x = k - 1 < NC ? (uint32_t)(c[k - 1 < NC ? k - 1 : 0] >> 32) : zero;
+      MW_ADDC(acc[k], x, cy);
+    }
+  MW_ADD_CO(acc[2], h[0], cy);
+#pragma unroll
+  for(int k = 3; k < A; ++k)
+    {
+      const uint32_t x = k - 2 < NC ? h[k - 2 < NC ? k - 2 : 0] : zero;
+      MW_ADDC(acc[k], x, cy);
+    }
+}
+// one of the three products over the RB staged rows: planes [P0, P0+M) of both operands
+template <int M, int RB, int PL>
+MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL * RB * 16], int p0, int li, int lj, uint32_t (&acc)[2 * M + 2])
+{
+  uint64_t c[2 * M - 1];
+  uint32_t h[2 * M - 1];
+#pragma unroll
+  for(int k = 0; k < 2 * M - 1; ++k)
+    {
+      c[k] = 0;
+      h[k] = 0;
+    }
+#pragma unroll 1
+  for(int rr = 0; rr < RB; ++rr)
+    {
+      uint32_t a[M], b[M];
+#pragma unroll
+      for(int l = 0; l < M; ++l)
+        {
+          a[l] = sa[((p0 + l) * RB + rr) * 16 + li];
+          b[l] = sb[((p0 + l) * RB + rr) * 16 + lj];
+        }
+      SyrkColumns<M, 0>::run(a, b, c, h);
+    }
+  syrk_fold<M>(acc, c, h);
+}
 
-// acc(i,j) (i >= j, tiles of 16x16) = sum_r fx(r,i) * fx(r,j), rows r in
+// acc(i,j) (i >= j, tiles of 16x16) = G(i,j) = sum_r a'(r,i) a'(r,j), rows r in
 // [0, nrows).  fx element (r,n) at r*N + n.  acc element (i,j) at i + j*N in
-// a (2FX+2)-plane limb-major two's-complement array.  Row chunks of RB rows are
+// a (2FX+2)-plane limb-major array of non-negative integers.  Row chunks of RB rows are
 // staged through LDS (limb-major, so lanes of a wavefront hit distinct banks for
-// the i operand and broadcast the j operand).
+// the i operand and broadcast the j operand).  The hot loop is nothing but
+// v_mad_u64_u32 + v_addc_co_u32 pairs: per chunk and product, 2M-1 column accumulators
+// run over the RB rows and are folded into that product's (2M+2)-limb sum once.
 // tile_list[t] = ti << 16 | tj (tj <= ti), built by syrk_tile_order().
+#ifndef SDPB_SYRK_WAVES
+#define SDPB_SYRK_WAVES (FX <= 16 ? 4 : 2)
+#endif
 template <int FX, int RB>
-__global__ void __launch_bounds__(WG, (FX <= 16 ? 4 : 2)) // up to 512 bits the accumulators fit 128 VGPRs: 4 waves per SIMD
+__global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   k_syrk_fx(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tile_list,
             int ntile)
 {
-  constexpr int W = 2 * FX + 2;
+  constexpr int M = FX / 2, A = 2 * M + 2, W = 2 * FX + 2, PL = fx_planes<FX>();
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), so XCD x is
   // given the contiguous range [x*per, (x+1)*per) of `tile_list`, which enumerates the
   // lower-triangle tiles in 8x8 super-blocks: the workgroups resident on one XCD share a
@@ -846,16 +1098,17 @@ __global__ void __launch_bounds__(WG, (FX <= 16 ? 4 : 2)) // up to 512 bits the 
   const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
   const int i = ti * 16 + li, j = tj * 16 + lj;
-  __shared__ uint32_t sa[(FX + 1) * RB * 16];
-  __shared__ uint32_t sb[(FX + 1) * RB * 16];
-  uint32_t a_acc[W];
+  __shared__ uint32_t sa[PL * RB * 16];
+  __shared__ uint32_t sb[PL * RB * 16];
+  uint32_t ll[A], hh[A], ss[A];
 #pragma unroll
-  for(int k = 0; k < W; ++k)
-    a_acc[k] = 0;
+  for(int k = 0; k < A; ++k)
+    ll[k] = hh[k] = ss[k] = 0;
   for(unsigned r0 = 0; r0 < nrows; r0 += RB)
     {
-      // stage: (FX+1) planes x RB rows x 16 columns for each operand
-      for(int e = threadIdx.x; e < (FX + 1) * RB * 16; e += WG)
+      // stage: PL planes x RB rows x 16 columns for each operand (rows past the end and
+      // columns past N read as zero limbs: they add nothing to any product)
+      for(int e = threadIdx.x; e < PL * RB * 16; e += WG)
         {
           const int col = e & 15, rr = (e >> 4) % RB, pl = (e >> 4) / RB;
           const unsigned r = r0 + rr;
@@ -866,56 +1119,88 @@ __global__ void __launch_bounds__(WG, (FX <= 16 ? 4 : 2)) // up to 512 bits the 
           sb[e] = (okr && cb < N) ? row[cb] : 0u;
         }
       __syncthreads();
-#pragma unroll 1
-      for(int rr = 0; rr < RB; ++rr)
-        {
-          uint32_t a[FX], b[FX];
-#pragma unroll
-          for(int l = 0; l < FX; ++l)
-            {
-              a[l] = sa[((l + 1) * RB + rr) * 16 + li];
-              b[l] = sb[((l + 1) * RB + rr) * 16 + lj];
-            }
-          const uint32_t sgn = sa[rr * 16 + li] ^ sb[rr * 16 + lj];
-          const uint32_t mask = 0u - sgn; // 0 or ~0
-          // product scanning; each finished column limb goes straight into acc as
-          // (limb ^ mask) with the two's-complement +1 folded into the first carry
-          uint64_t lo = 0;
-          uint32_t hi = 0;
-          uint32_t carry = sgn;
-          SyrkColumns<FX, 0>::run(a, b, lo, hi, a_acc, mask, carry);
-          {
-            const uint32_t limb = (uint32_t)lo ^ mask;
-            const uint64_t s = (uint64_t)a_acc[2 * FX - 1] + limb + carry;
-            a_acc[2 * FX - 1] = (uint32_t)s;
-            carry = (uint32_t)(s >> 32);
-          }
-#pragma unroll
-          for(int k = 2 * FX; k < W; ++k)
-            {
-              const uint64_t s = (uint64_t)a_acc[k] + mask + carry;
-              a_acc[k] = (uint32_t)s;
-              carry = (uint32_t)(s >> 32);
-            }
-        }
+      syrk_rows<M, RB, PL>(sa, sb, 0, li, lj, ll);
+      syrk_rows<M, RB, PL>(sa, sb, M, li, lj, hh);
+      syrk_rows<M, RB, PL>(sa, sb, 2 * M, li, lj, ss);
       __syncthreads();
     }
   if(i < N && j <= i)
     {
+      // ss <- SS - LL - HH (>= 0), then G = LL + ss B + HH B^2, B = 2^(32M-1)
+      uint64_t bw = 0;
+#pragma unroll
+      for(int k = 0; k < A; ++k)
+        {
+          const uint64_t d = (uint64_t)ss[k] - (uint64_t)ll[k] - bw;
+          ss[k] = (uint32_t)d;
+          bw = (d >> 63) & 1u;
+        }
+      bw = 0;
+#pragma unroll
+      for(int k = 0; k < A; ++k)
+        {
+          const uint64_t d = (uint64_t)ss[k] - (uint64_t)hh[k] - bw;
+          ss[k] = (uint32_t)d;
+          bw = (d >> 63) & 1u;
+        }
+      uint32_t w[W];
+#pragma unroll
+      for(int k = 0; k < W; ++k)
+        w[k] = k < A ? ll[k < A ? k : 0] : 0u;
+      add_shifted<W, A>(w, ss, 32 * M - 1, false);
+      add_shifted<W, A>(w, hh, 64 * M - 2, false);
       const size_t o = (size_t)i + (size_t)j * N;
 #pragma unroll
       for(int k = 0; k < W; ++k)
-        acc[(size_t)k * acc_stride + o] = a_acc[k];
+        acc[(size_t)k * acc_stride + o] = w[k];
     }
 }
 
-// Q(i,j) = (acc(i,j) / 2^(64 FX)) * norm_i * norm_j for i >= j; checks the diagonal
-// (check_normalized_Q_diagonal, compute_Q.cxx:65-91): |Q'_ii - 1| < 2^(-16 FX).
+// Remove the bias in place (after any cross-GPU sum): for i >= j
+//   acc(i,j) <- G(i,j) - C (S_i + S_j) + n C^2 = sum_r v_ri v_rj   (two's complement),
+// C = 2^FB, n = total number of rows, S behind the N x N block (k_fx_colsum).
+template <int FX>
+__global__ void __launch_bounds__(WG) k_syrk_unbias(uint32_t *acc, size_t acc_stride, int N, unsigned long long nrows_total)
+{
+  constexpr int W = 2 * FX + 2, FB = fx_frac_bits<FX>();
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)N * N)
+    return;
+  const int i = (int)(idx % N), j = (int)(idx / N);
+  if(i < j)
+    return;
+  uint32_t w[W], s[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    w[k] = acc[(size_t)k * acc_stride + idx];
+  {
+    uint64_t cy = 0;
+#pragma unroll
+    for(int k = 0; k < W; ++k)
+      {
+        const uint64_t t = (uint64_t)acc[(size_t)k * acc_stride + (size_t)N * N + i] + acc[(size_t)k * acc_stride + (size_t)N * N + j] + cy;
+        s[k] = (uint32_t)t;
+        cy = t >> 32;
+      }
+  }
+  add_shifted<W, W>(w, s, FB, true);
+  {
+    const uint32_t nn[2] = {(uint32_t)nrows_total, (uint32_t)(nrows_total >> 32)};
+    add_shifted<W, 2>(w, nn, 2 * FB, false);
+  }
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    acc[(size_t)k * acc_stride + idx] = w[k];
+}
+
+// Q(i,j) = (acc(i,j) / 2^(2FB)) * norm_i * norm_j for i >= j (acc unbiased, signed);
+// checks the diagonal (check_normalized_Q_diagonal, compute_Q.cxx:65-91):
+// |Q'_ii - 1| < 2^(-16 FX).
 template <int NL, int FX>
 __global__ void __launch_bounds__(WG)
   k_restore_Q(const uint32_t *acc, size_t acc_stride, int N, mw::CPtr norms, mw::Ptr Q, int *diag_fail)
 {
-  constexpr int W = 2 * FX + 2;
+  constexpr int W = 2 * FX + 2, FB = fx_frac_bits<FX>();
   const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
   if(idx >= (size_t)N * N)
     return;
@@ -936,12 +1221,12 @@ __global__ void __launch_bounds__(WG)
 #pragma unroll
       for(int k = 0; k < W; ++k)
         {
-          const uint64_t s = (uint64_t)(~w[k]) + carry;
-          w[k] = (uint32_t)s;
-          carry = (uint32_t)(s >> 32);
+          const uint64_t t = (uint64_t)(~w[k]) + carry;
+          w[k] = (uint32_t)t;
+          carry = (uint32_t)(t >> 32);
         }
     }
-  // magnitude w as a W-limb integer; value = w / 2^(64FX) = (w / 2^(32W)) * 2^(32W - 64FX)
+  // magnitude w as a W-limb integer; value = w / 2^(2FB) = (w / 2^(32W)) * 2^(32W - 2FB)
   uint32_t zl = 0, topw = 0;
   bool found = false;
 #pragma unroll
@@ -963,7 +1248,7 @@ __global__ void __launch_bounds__(WG)
 #pragma unroll
       for(int k = 0; k < NL; ++k)
         v.m[k] = (W - NL + k >= 0) ? w[W - NL + k >= 0 ? W - NL + k : 0] : 0u;
-      v.e = 32 * W - 64 * FX - (int32_t)(32u * zl + c);
+      v.e = 32 * W - 2 * FB - (int32_t)(32u * zl + c);
       v.neg = negative;
     }
   const Mw<NL> ni = mw::load<NL>(norms, i);

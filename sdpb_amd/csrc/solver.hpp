@@ -164,6 +164,7 @@ template <int NL> class Solver : public SolverBase
   std::vector<BlockDesc> blk_;
   int Jl_ = 0;
   size_t Ptot_ = 0;        // local sum of P_j
+  unsigned long long Ptot_global_ = 0; // sum over all ranks
   size_t psd_elems_ = 0, psd_rows_local_ = 0;
   long total_psd_rows_ = 0; // global (step.cxx:143)
   hipStream_t stream_ = nullptr;
@@ -185,7 +186,8 @@ template <int NL> class Solver : public SolverBase
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
-  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_;
+  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_, colsum_partial_;
+  unsigned colsum_slices_ = 1;
   DevBuf<double> eigF_;
   DevBuf<unsigned long long> acc64_;
   DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
@@ -272,6 +274,7 @@ private:
         const int m = dims_[j], K = npts_[j];
         const int n0 = m * ((K + 1) / 2), n1 = m * K - n0;
         total_psd_rows_ += n0 + n1;
+        Ptot_global_ += (unsigned long long)K * m * (m + 1) / 2;
         if(owner_[j] != rank_)
           continue;
         local_.push_back(j);
@@ -374,9 +377,11 @@ private:
     ratio_.alloc((size_t)5 * std::max(Jl_, 1) + 1, NL);
     scal_.alloc(S_COUNT, NL);
     fx_stride_ = off_bt ? off_bt : 1;
-    fx_.alloc(fx_stride_ * (FX + 1));
-    acc_stride_ = (size_t)N_ * N_;
+    fx_.alloc(fx_stride_ * fx_planes<FX>());
+    acc_stride_ = (size_t)N_ * N_ + N_; // N x N outputs + N column sums (k_fx_colsum)
     acc_.alloc(acc_stride_ * ACCW);
+    colsum_slices_ = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv(Ptot_, 64)));
+    colsum_partial_.alloc((size_t)colsum_slices_ * 2 * (FX / 2 + 2) * N_);
     syrk_tiles_.upload(syrk_tile_order(N_));
     if(world_ > 1)
       {
@@ -451,7 +456,7 @@ public:
     const double fx_bytes = (double)Ptot_ * N_ * (FX + 1) * 4.0, acc_bytes = (double)N_ * (N_ + 1) / 2 * ACCW * 4.0;
     ss << (first ? "" : ", ") << "\"kernel.k_syrk_fx.ms\": " << syrk_kernel_ms_ << ", \"kernel.k_syrk_fx.launches\": " << syrk_launches_
        << ", \"kernel.k_syrk_fx.algorithmic_bytes\": " << (fx_bytes + acc_bytes)
-       << ", \"kernel.k_syrk_fx.limb_macs\": " << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX;
+       << ", \"kernel.k_syrk_fx.limb_macs\": " << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * 0.75; // executed: 3 (FX/2)^2 per product
     ss << "}";
     return ss.str();
   }
@@ -952,6 +957,7 @@ private:
       const unsigned tiles = cdiv(N_, 16);
       if(cnt)
         {
+          syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_);
           // HIP events on the launch stream bracket the dominant kernel (bench.py roofline)
           HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
           launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_,
@@ -969,10 +975,19 @@ private:
         reduce_Q_accumulators();
       int *qflags = flags_.p + 2 * std::max(Jl_, 1);
       HIP_CHECK(hipMemsetAsync(qflags, 0, 4 * sizeof(int), stream_));
+      launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, acc_.p, acc_stride_, N_, Ptot_global_);
       launch(k_restore_Q<NL, FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_,
              norms_.cptr(), Q_.ptr(), qflags + 1);
     }
     cholesky_Q_async();
+  }
+  // S_n = sum_r a'_rn behind the N x N block of acc (kernels.hpp: k_fx_colsum)
+  void syrk_column_sums(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, uint32_t *partial,
+                        unsigned slices)
+  {
+    const unsigned rows_per_slice = cdiv(nrows, slices);
+    launch(k_fx_colsum<FX>, dim3(cdiv(N, 64), slices), dim3(WG), stream_, fx, fx_stride, nrows, N, rows_per_slice, partial);
+    launch(k_fx_colsum_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride);
   }
   // exact cross-GPU sum of the fixed-point Q' images
   void reduce_Q_accumulators()
@@ -1445,7 +1460,7 @@ public:
     if((int)tok.size() != rows * cols)
       throw SolverError(4, "op_int_syrk: wrong element count");
     const size_t cnt = (size_t)rows * cols;
-    std::vector<uint32_t> h(cnt * (FX + 1), 0);
+    std::vector<uint32_t> h(cnt * (FX + 1), 0); // plane 0 = sign, planes 1..FX = magnitude
     for(int c = 0; c < cols; ++c)
       for(int r = 0; r < rows; ++r)
         {
@@ -1469,22 +1484,28 @@ public:
               else
                 n.mul_small(10, (uint32_t)(*s - '0'));
             }
-          if(n.w.size() > (size_t)FX)
-            throw SolverError(4, "op_int_syrk: |value| >= 2^(32*FX)");
+          if(n.w.size() > (size_t)FX || (n.w.size() == (size_t)FX && (n.w[FX - 1] >> 29) != 0))
+            throw SolverError(4, "op_int_syrk: |value| >= 2^(32*FX-3)");
           const size_t idx = (size_t)r * cols + c; // fx element (r, n) at r*N + n
           for(size_t k = 0; k < n.w.size(); ++k)
             h[(k + 1) * cnt + idx] = n.w[k];
           h[idx] = (negative && !n.w.empty()) ? 1u : 0u;
         }
-    DevBuf<uint32_t> fx, acc;
-    fx.upload(h);
-    const size_t as = (size_t)cols * cols;
+    DevBuf<uint32_t> staged, fx, acc, partial;
+    staged.upload(h);
+    fx.alloc(cnt * fx_planes<FX>());
+    launch(k_fx_from_int<FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, (const uint32_t *)staged.p, cnt, fx.p, cnt);
+    const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
+    const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
+    partial.alloc((size_t)slices * 2 * (FX / 2 + 2) * cols);
+    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices);
     const unsigned tiles = cdiv(cols, 16);
     DevBuf<uint32_t> tl;
     tl.upload(syrk_tile_order(cols));
     launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx.p, cnt, (unsigned)rows,
            cols, acc.p, as, (const uint32_t *)tl.p, (int)(tiles * (tiles + 1) / 2));
+    launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows);
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<uint32_t> a = acc.download();
     std::string out;

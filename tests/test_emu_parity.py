@@ -30,14 +30,18 @@ def test_emulated_int_syrk_is_exact():
     import random
     from oracle.oracle import Oracle
     sdp, meta, _, _ = parity.load_case("1d")
-    s = SDPSolver(sdp, 128, lib_path=libs.emu_lib())  # NL=6 -> FX=4: |v| < 2^128
+    s = SDPSolver(sdp, 128, lib_path=libs.emu_lib())  # NL=6 -> FX=4: |v| < 2^(32 FX - 3) = 2^125
     o = Oracle(sdp, 128)
     rng = random.Random(7)
     rows, cols = 37, 21
-    vals = [rng.randrange(-(2 ** 128) + 1, 2 ** 128) for _ in range(rows * cols)]
+    vals = [rng.randrange(-(2 ** 125) + 1, 2 ** 125) for _ in range(rows * cols)]
     vals[5] = 0
-    vals[11] = 2 ** 128 - 1
-    vals[12] = -(2 ** 128) + 1
+    vals[11] = 2 ** 125 - 1
+    vals[12] = -(2 ** 125) + 1
+    vals[13] = 1
+    vals[14] = -1
+    vals[15] = 2 ** 63            # exactly the Karatsuba split point 2^(32 M - 1)
+    vals[16] = -(2 ** 63) + 1
     got = s.op_int_syrk(rows, cols, vals)
     want = o.int_syrk(rows, cols, vals)  # upper triangle, column-major
     for j in range(cols):

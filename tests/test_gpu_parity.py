@@ -43,11 +43,14 @@ def test_int_syrk_bit_exact(precision, rows, cols):
     sdp, _, _, _ = parity.load_case("1d")
     s = _solver(sdp, precision)
     o = Oracle(sdp, precision)
-    fxbits = 32 * (s.limbs - 2)
+    fxbits = 32 * (s.limbs - 2) - 3   # kernels.hpp: fx_frac_bits (bias + carry-free Karatsuba sum)
     rng = random.Random(rows * cols)
     vals = [rng.randrange(-(2 ** fxbits) + 1, 2 ** fxbits) for _ in range(rows * cols)]
     vals[0] = 0
     vals[-1] = 2 ** fxbits - 1
+    vals[1] = -(2 ** fxbits) + 1
+    vals[2] = 2 ** (fxbits // 2)
+    vals[3] = -1
     got = s.op_int_syrk(rows, cols, vals)
     want = o.int_syrk(rows, cols, vals)
     for j in range(cols):
