@@ -125,10 +125,96 @@ template <int NL, int OP, class F> __global__ void __launch_bounds__(WG) k_reduc
 #define SDPB_PB 32
 #endif
 constexpr int PB = SDPB_PB; // panel width (tests also build a PB = 4 variant to exercise ragged multi-panel paths)
-constexpr int CI_T = 512; // lanes of the diagonal-block kernel
+constexpr int CI_T = 256;      // lanes of the diagonal-block kernel: one wavefront per SIMD of a CU
+constexpr int CI_D0 = CI_T - 64; // first lane of the wavefront that owns the diagonal
+constexpr int CI_NPK = PB * (PB + 1) / 2;                             // packed lower triangle (LDS images)
+constexpr int CI_E = (PB * (PB - 1) / 2 + CI_D0 - 1) / CI_D0;         // off-diagonal elements per lane
+static_assert(PB <= 64 && CI_E <= 3, "k_chol_inv_lds: element-to-lane mapping");
+
+// limb-major LDS image of a packed triangle (conflict-free for consecutive elements)
+template <int NL> MW_HD Mw<NL> ci_ld(const uint32_t *s, int idx)
+{
+  Mw<NL> v;
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    v.m[l] = s[l * CI_NPK + idx];
+  v.e = (int32_t)s[NL * CI_NPK + idx];
+  v.neg = s[(NL + 1) * CI_NPK + idx];
+  return v;
+}
+template <int NL> MW_HD void ci_st(uint32_t *s, int idx, const Mw<NL> &v)
+{
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    s[l * CI_NPK + idx] = v.m[l];
+  s[NL * CI_NPK + idx] = (uint32_t)v.e;
+  s[(NL + 1) * CI_NPK + idx] = v.neg;
+}
+
+// One element (r,c), r > c, of a diagonal block, or a diagonal element (r == c).
+template <int NL> struct CiElem
+{
+  int r, c; // r < 0: no element
+  Acc<NL> acc;
+};
+#define SDPB_PK(r, c) ((c) * n - (c) * ((c)-1) / 2 + ((r) - (c)))
+// element number idx of the strictly lower triangle, column by column
+template <int NL> MW_HD void ci_init_offdiag(CiElem<NL> &el, int idx, int n, const Batch &A, const MatDesc &d, int k0)
+{
+  int c = 0, off = 0;
+  while(c < n - 2 && off + (n - 1 - c) <= idx)
+    {
+      off += n - 1 - c;
+      ++c;
+    }
+  el.c = c;
+  el.r = idx < n * (n - 1) / 2 ? c + 1 + (idx - off) : -1;
+  el.acc = mw::acc_zero<NL>();
+  if(el.r >= 0)
+    mw::acc_add(el.acc, mat_ld<NL>(A, d, k0 + el.r, k0 + c));
+}
+// (2) finish column k of L and row k of X:  L(r,k) = acc / L_kk,  X(k,c) = -acc / L_kk
+template <int NL> MW_HD void ci_finish(CiElem<NL> &el, int k, int n, uint32_t *sL, uint32_t *sX, const uint32_t *s_inv)
+{
+  const bool colk = el.c == k && el.r > k, rowk = el.r == k && el.c < k;
+  if(!(colk || rowk))
+    return;
+  Mw<NL> inv;
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    inv.m[l] = s_inv[l];
+  inv.e = (int32_t)s_inv[NL];
+  inv.neg = s_inv[NL + 1];
+  Mw<NL> v = mw::mul(mw::acc_result(el.acc), inv);
+  v.neg ^= (rowk && !mw::is_zero(v)) ? 1u : 0u;
+  ci_st<NL>(rowk ? sX : sL, SDPB_PK(el.r, el.c), v); // one code path for both kinds (lanes of a wavefront hold both)
+  el.acc = mw::acc_zero<NL>();
+}
+// (3) one product for an element below row k: trailing update (c > k) acc -= L(r,k) L(c,k),
+// inverse (c <= k) acc += L(r,k) X(k,c) — one code path
+template <int NL> MW_HD void ci_update(CiElem<NL> &el, int k, int n, const uint32_t *sL, const uint32_t *sX)
+{
+  if(el.r <= k)
+    return;
+  const bool trail = el.c > k;
+  const Mw<NL> lrk = ci_ld<NL>(sL, SDPB_PK(el.r, k));
+  const Mw<NL> other = ci_ld<NL>(trail ? sL : sX, trail ? SDPB_PK(el.c, k) : SDPB_PK(k, el.c));
+  mw::acc_fma(el.acc, lrk, other, trail ? 1u : 0u);
+}
 
 // Diagonal block p of every matrix: A_pp = L L^T in place (upper part zeroed),
-// Li_pp = L^{-1}, invd = 1/L_ii.  fail[q] = 1 + index of a non-positive pivot.
+// Li_pp = X = L^{-1}, invd = 1/L_ii.  fail[q] = 1 + index of a non-positive pivot.
+// Every element (r,c) of the lower triangle is owned by one lane and lives in a
+// register accumulator (mw::Acc: one aligned add per term, no normalisation) that is
+// used twice: until pivot c it collects A(r,c) - sum_{k<c} L(r,k) L(c,k); after it
+// has been finished into L(r,c) it collects sum_{c<=k<r} L(r,k) X(k,c), finished at
+// pivot r into X(r,c) = -acc / L_rr.  Per pivot k: (1) the owner of (k,k) takes the
+// reciprocal square root — the only long dependent chain, ~9 us at 576 bits — (2) column
+// k of L and row k of X are finished and published in LDS, (3) every element below row
+// k absorbs exactly one product.  The diagonal has a wavefront of its own (lane
+// CI_D0 + k owns (k,k)) whose step (3) is a single product, and there is no barrier
+// between (3) and the next (1): the next rsqrt starts while the other wavefronts are
+// still busy with their three products per lane.
 template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A, Batch invd, Batch Li, int p, int *fail)
 {
   const int q = blockIdx.x;
@@ -137,35 +223,53 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
   if(k0 >= d.rows)
     return;
   const int n = d.rows - k0 < PB ? d.rows - k0 : PB;
-  __shared__ Mw<NL> sL[PB * (PB + 1) / 2], sI[PB * (PB + 1) / 2];
-  __shared__ Mw<NL> s_inv;
+  __shared__ uint32_t sL[(NL + 2) * CI_NPK], sX[(NL + 2) * CI_NPK];
+  __shared__ uint32_t s_inv[NL + 2];
   __shared__ int s_fail;
-#define SDPB_PK(r, c) ((c) * n - (c) * ((c)-1) / 2 + ((r) - (c)))
-  for(int idx = t; idx < n * n; idx += CI_T)
+  // the lane's elements, as separate objects so that the accumulators stay in registers
+  CiElem<NL> e0, e1, e2;
+  e0.r = e1.r = e2.r = -1;
+  e0.c = e1.c = e2.c = 0;
+  const bool diag_lane = t >= CI_D0;
+  if(diag_lane)
     {
-      const int c = idx / n, r = idx % n;
-      if(r >= c)
+      // e0 is the diagonal element (t - CI_D0); the other two stay empty
+      const int k = t - CI_D0;
+      e0.acc = mw::acc_zero<NL>();
+      if(k < n)
         {
-          sL[SDPB_PK(r, c)] = mat_ld<NL>(A, d, k0 + r, k0 + c);
-          sI[SDPB_PK(r, c)] = r == c ? mw::from_u32<NL>(1) : mw::zero<NL>();
+          e0.r = e0.c = k;
+          mw::acc_add(e0.acc, mat_ld<NL>(A, d, k0 + k, k0 + k));
         }
+    }
+  else
+    {
+      ci_init_offdiag<NL>(e0, t, n, A, d, k0);
+      if constexpr(CI_E > 1)
+        ci_init_offdiag<NL>(e1, t + CI_D0, n, A, d, k0);
+      if constexpr(CI_E > 2)
+        ci_init_offdiag<NL>(e2, t + 2 * CI_D0, n, A, d, k0);
     }
   if(t == 0)
     s_fail = 0;
   __syncthreads();
-  for(int j = 0; j < n; ++j)
+  for(int k = 0; k < n; ++k)
     {
-      if(t == 0)
+      // (1) pivot: X_kk = 1/L_kk = rsqrt(d_k)
+      Mw<NL> dk = mw::zero<NL>();
+      if(diag_lane && e0.r == k)
         {
-          const Mw<NL> dj = sL[SDPB_PK(j, j)];
-          if(mw::is_zero(dj) || dj.neg)
-            s_fail = k0 + j + 1;
+          dk = mw::acc_result(e0.acc);
+          if(mw::is_zero(dk) || dk.neg)
+            s_fail = k0 + k + 1;
           else
             {
-              const Mw<NL> r = mw::rsqrt(dj);
-              sL[SDPB_PK(j, j)] = mw::mul(dj, r);
-              s_inv = r;
-              mw::store<NL>(invd.p, (size_t)dv.off + k0 + j, r);
+              const Mw<NL> r = mw::rsqrt(dk);
+#pragma unroll
+              for(int l = 0; l < NL; ++l)
+                s_inv[l] = r.m[l];
+              s_inv[NL] = (uint32_t)r.e;
+              s_inv[NL + 1] = r.neg;
             }
         }
       __syncthreads();
@@ -175,41 +279,55 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
             fail[q] = s_fail;
           return;
         }
-      const Mw<NL> inv = s_inv;
-      for(int i = j + 1 + t; i < n; i += CI_T)
-        sL[SDPB_PK(i, j)] = mw::mul(sL[SDPB_PK(i, j)], inv);
-      __syncthreads();
-      const int m = n - j - 1;
-      for(int idx = t; idx < m * m; idx += CI_T)
+      // (2) column k of L, row k of X; the diagonal owner (off the critical path now) L_kk = d_k / L_kk
+      if(diag_lane)
         {
-          const int c = j + 1 + idx / m, r = j + 1 + idx % m;
-          if(r >= c)
-            sL[SDPB_PK(r, c)] = mw::fms(sL[SDPB_PK(r, j)], sL[SDPB_PK(c, j)], sL[SDPB_PK(r, c)]);
+          if(e0.r == k)
+            {
+              Mw<NL> inv;
+#pragma unroll
+              for(int l = 0; l < NL; ++l)
+                inv.m[l] = s_inv[l];
+              inv.e = (int32_t)s_inv[NL];
+              inv.neg = s_inv[NL + 1];
+              ci_st<NL>(sL, SDPB_PK(k, k), mw::mul(dk, inv));
+              ci_st<NL>(sX, SDPB_PK(k, k), inv);
+              mw::store<NL>(invd.p, (size_t)dv.off + k0 + k, inv);
+            }
+        }
+      else
+        {
+          ci_finish<NL>(e0, k, n, sL, sX, s_inv);
+          if constexpr(CI_E > 1)
+            ci_finish<NL>(e1, k, n, sL, sX, s_inv);
+          if constexpr(CI_E > 2)
+            ci_finish<NL>(e2, k, n, sL, sX, s_inv);
         }
       __syncthreads();
-    }
-  // inverse by forward substitution on the identity, one team of G lanes per column:
-  //   x_k = x_k / L_kk ; x_i -= L_ik x_k (i > k)
-  const int G = CI_T / PB, c = t / G, g = t % G;
-  for(int k = 0; k < n; ++k)
-    {
-      if(g == 0 && c <= k && c < n)
-        sI[SDPB_PK(k, c)] = mw::mul(sI[SDPB_PK(k, c)], mw::load<NL>(invd.p, (size_t)dv.off + k0 + k));
-      __syncthreads();
-      if(c <= k && c < n)
+      // (3) one product per element below row k
+      if(diag_lane)
         {
-          const Mw<NL> xk = sI[SDPB_PK(k, c)];
-          if(!mw::is_zero(xk))
-            for(int i = k + 1 + g; i < n; i += G)
-              sI[SDPB_PK(i, c)] = mw::fms(sL[SDPB_PK(i, k)], xk, sI[SDPB_PK(i, c)]);
+          if(e0.r > k)
+            {
+              const Mw<NL> l = ci_ld<NL>(sL, SDPB_PK(e0.r, k));
+              mw::acc_fma(e0.acc, l, l, 1u);
+            }
         }
-      __syncthreads();
+      else
+        {
+          ci_update<NL>(e0, k, n, sL, sX);
+          if constexpr(CI_E > 1)
+            ci_update<NL>(e1, k, n, sL, sX);
+          if constexpr(CI_E > 2)
+            ci_update<NL>(e2, k, n, sL, sX);
+        }
     }
+  __syncthreads();
   for(int idx = t; idx < n * n; idx += CI_T)
     {
       const int cc = idx / n, r = idx % n;
-      mat_st<NL>(A, d, k0 + r, k0 + cc, r >= cc ? sL[SDPB_PK(r, cc)] : mw::zero<NL>());
-      mat_st<NL>(Li, di, k0 + r, k0 + cc, r >= cc ? sI[SDPB_PK(r, cc)] : mw::zero<NL>());
+      mat_st<NL>(A, d, k0 + r, k0 + cc, r >= cc ? ci_ld<NL>(sL, SDPB_PK(r, cc)) : mw::zero<NL>());
+      mat_st<NL>(Li, di, k0 + r, k0 + cc, r >= cc ? ci_ld<NL>(sX, SDPB_PK(r, cc)) : mw::zero<NL>());
     }
 #undef SDPB_PK
 }
