@@ -14,6 +14,7 @@
 #include "dev.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace sdpb
@@ -1159,6 +1160,11 @@ template <int M> MW_HD void syrk_fold(uint32_t (&acc)[2 * M + 2], const uint64_t
       MW_ADDC(acc[k], x, cy);
     }
 }
+#ifndef SDPB_SYRK_UNROLL
+#define SDPB_SYRK_UNROLL 2
+#endif
+#define SDPB_STR_(x) #x
+#define SDPB_UNROLL(n) _Pragma(SDPB_STR_(unroll n))
 // one of the three products over the RB staged rows: planes [P0, P0+M) of both operands
 template <int M, int RB, int PL>
 MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL * RB * 16], int p0, int li, int lj, uint32_t (&acc)[2 * M + 2])
@@ -1171,7 +1177,7 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
       c[k] = 0;
       h[k] = 0;
     }
-#pragma unroll 1
+  SDPB_UNROLL(SDPB_SYRK_UNROLL)
   for(int rr = 0; rr < RB; ++rr)
     {
       uint32_t a[M], b[M];
@@ -1194,24 +1200,53 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
 // v_mad_u64_u32 + v_addc_co_u32 pairs: per chunk and product, 2M-1 column accumulators
 // run over the RB rows and are folded into that product's (2M+2)-limb sum once.
 // tile_list[t] = ti << 16 | tj (tj <= ti), built by syrk_tile_order().
+// Row splits: workgroup (tile, split) covers rows [split * rows_per_split, ...) and writes
+// its partial G to part + split * W * acc_stride (k_syrk_reduce adds the splits); with
+// one split the output goes straight to acc.  The host picks nsplit so that
+// tiles * nsplit fills a whole number of rounds of resident workgroups (syrk_row_splits).
 #ifndef SDPB_SYRK_WAVES
-#define SDPB_SYRK_WAVES (FX <= 16 ? 4 : 2)
+#define SDPB_SYRK_WAVES (FX <= 16 ? 4 : 2) // measured: 4 waves without splits beat 3 waves with splits at N = 1000
 #endif
+template <int FX> constexpr int syrk_waves_per_simd() { return SDPB_SYRK_WAVES; }
+// nsplit in [1, 16]: fewest splits within 2% of the best occupancy of the last round
+inline int syrk_row_splits(int ntile, unsigned nrows, int slots, int rb)
+{
+  if(const char *env = std::getenv("SDPB_HIP_SYRK_SPLITS")) // tests force the split path on small inputs
+    return std::max(1, std::min(16, std::atoi(env)));
+  int best = 1;
+  double best_eff = 0;
+  for(int s = 1; s <= 16; ++s)
+    {
+      if(s > 1 && nrows / (unsigned)s < 64u * (unsigned)rb)
+        break;
+      const double items = (double)ntile * s, rounds = std::ceil(items / slots), eff = items / (rounds * slots);
+      if(eff > best_eff + 0.02)
+        {
+          best = s;
+          best_eff = eff;
+        }
+    }
+  return best;
+}
 template <int FX, int RB>
 __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   k_syrk_fx(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tile_list,
-            int ntile)
+            int ntile, int nsplit, unsigned rows_per_split)
 {
   constexpr int M = FX / 2, A = 2 * M + 2, W = 2 * FX + 2, PL = fx_planes<FX>();
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), so XCD x is
-  // given the contiguous range [x*per, (x+1)*per) of `tile_list`, which enumerates the
-  // lower-triangle tiles in 8x8 super-blocks: the workgroups resident on one XCD share a
-  // few row and column panels of P' in that XCD's 4-MiB L2 (placement affects speed
-  // only, never correctness).
-  const int per = (ntile + 7) / 8;
-  const int tile = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
-  if((int)(blockIdx.x / 8) >= per || tile >= ntile)
+  // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch), so XCD x is given
+  // the contiguous range [x*per, (x+1)*per) of the items (split, tile), tiles enumerated
+  // by `tile_list` in 8x8 super-blocks: the workgroups resident on one XCD share a few row
+  // and column panels of P' in that XCD's 4-MiB L2 (placement affects speed only, never
+  // correctness).
+  const int nitem = ntile * nsplit, per = (nitem + 7) / 8;
+  const int item = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+  if((int)(blockIdx.x / 8) >= per || item >= nitem)
     return;
+  const int split = item / ntile, tile = item % ntile;
+  const unsigned row_begin = (unsigned)split * rows_per_split;
+  const unsigned row_end = (row_begin + rows_per_split < nrows && split + 1 < nsplit) ? row_begin + rows_per_split : nrows;
+  acc += (size_t)split * W * acc_stride;
   const uint32_t tt = tile_list[tile];
   const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
@@ -1222,7 +1257,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 #pragma unroll
   for(int k = 0; k < A; ++k)
     ll[k] = hh[k] = ss[k] = 0;
-  for(unsigned r0 = 0; r0 < nrows; r0 += RB)
+  for(unsigned r0 = row_begin; r0 < row_end; r0 += RB)
     {
       // stage: PL planes x RB rows x 16 columns for each operand (rows past the end and
       // columns past N read as zero limbs: they add nothing to any product)
@@ -1231,7 +1266,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
           const int col = e & 15, rr = (e >> 4) % RB, pl = (e >> 4) / RB;
           const unsigned r = r0 + rr;
           const int ca = ti * 16 + col, cb = tj * 16 + col;
-          const bool okr = r < nrows;
+          const bool okr = r < row_end;
           const uint32_t *row = fx + (size_t)pl * fx_stride + (size_t)r * (size_t)N;
           sa[e] = (okr && ca < N) ? row[ca] : 0u;
           sb[e] = (okr && cb < N) ? row[cb] : 0u;
@@ -1271,6 +1306,24 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 #pragma unroll
       for(int k = 0; k < W; ++k)
         acc[(size_t)k * acc_stride + o] = w[k];
+    }
+}
+
+// acc(i,j) = sum over the row splits of part[split](i,j)  (i >= j)
+template <int FX> __global__ void __launch_bounds__(WG) k_syrk_reduce(const uint32_t *part, int nsplit, uint32_t *acc, size_t acc_stride, int N)
+{
+  constexpr int W = 2 * FX + 2;
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)N * N || (int)(idx % N) < (int)(idx / N))
+    return;
+  uint64_t cy = 0;
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    {
+      for(int s = 0; s < nsplit; ++s)
+        cy += part[((size_t)s * W + k) * acc_stride + idx];
+      acc[(size_t)k * acc_stride + idx] = (uint32_t)cy;
+      cy >>= 32;
     }
 }
 

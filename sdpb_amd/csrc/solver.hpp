@@ -186,7 +186,8 @@ template <int NL> class Solver : public SolverBase
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
-  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_, colsum_partial_;
+  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_, colsum_partial_, syrk_part_;
+  int num_cus_ = 256;
   unsigned colsum_slices_ = 1;
   DevBuf<double> eigF_;
   DevBuf<unsigned long long> acc64_;
@@ -233,6 +234,13 @@ public:
     if(N <= 0 || J_ <= 0)
       throw SolverError(4, "sdpb_hip_create: need at least one block and N >= 1");
     owner_ = plan_block_owners(dims, num_points, N, world);
+    {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      HIP_CHECK(hipGetDevice(&dev));
+      HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     HIP_CHECK(hipStreamCreate(&stream_));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_q_, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreate(&ev_q_ready_));
@@ -380,6 +388,13 @@ private:
     fx_.alloc(fx_stride_ * fx_planes<FX>());
     acc_stride_ = (size_t)N_ * N_ + N_; // N x N outputs + N column sums (k_fx_colsum)
     acc_.alloc(acc_stride_ * ACCW);
+    {
+      // partial outputs of the row-split syrk (sized once, here, not inside the iteration)
+      const unsigned tiles = cdiv(N_, 16);
+      const int nsplit = syrk_row_splits((int)(tiles * (tiles + 1) / 2), (unsigned)Ptot_, num_cus_ * syrk_waves_per_simd<FX>(), SYRK_RB);
+      if(nsplit > 1)
+        syrk_part_.alloc((size_t)nsplit * ACCW * acc_stride_);
+    }
     colsum_slices_ = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv(Ptot_, 64)));
     colsum_partial_.alloc((size_t)colsum_slices_ * 2 * (FX / 2 + 2) * N_);
     syrk_tiles_.upload(syrk_tile_order(N_));
@@ -960,8 +975,7 @@ private:
           syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_);
           // HIP events on the launch stream bracket the dominant kernel (bench.py roofline)
           HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
-          launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx_.p, fx_stride_,
-                 (unsigned)Ptot_, N_, acc_.p, acc_stride_, (const uint32_t *)syrk_tiles_.p, (int)(tiles * (tiles + 1) / 2));
+          syrk_G(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, (const uint32_t *)syrk_tiles_.p, syrk_part_);
           HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
           HIP_CHECK(hipEventSynchronize(ev_syrk1_));
           float ms = 0;
@@ -980,6 +994,28 @@ private:
              norms_.cptr(), Q_.ptr(), qflags + 1);
     }
     cholesky_Q_async();
+  }
+  // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
+  // that fills the last round of resident workgroups better; `part` grows on demand
+  void syrk_G(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tiles_dev,
+              DevBuf<uint32_t> &part)
+  {
+    const unsigned tiles = cdiv(N, 16);
+    const int ntile = (int)(tiles * (tiles + 1) / 2);
+    const int slots = num_cus_ * syrk_waves_per_simd<FX>();
+    const int nsplit = syrk_row_splits(ntile, nrows, slots, SYRK_RB);
+    const unsigned rps = cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB;
+    uint32_t *out = acc;
+    if(nsplit > 1)
+      {
+        if(part.n < (size_t)nsplit * ACCW * acc_stride)
+          part.alloc((size_t)nsplit * ACCW * acc_stride);
+        out = part.p;
+      }
+    launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
+           tiles_dev, ntile, nsplit, rps);
+    if(nsplit > 1)
+      launch(k_syrk_reduce<FX>, dim3(cdiv((size_t)N * N, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, acc, acc_stride, N);
   }
   // S_n = sum_r a'_rn behind the N x N block of acc (kernels.hpp: k_fx_colsum)
   void syrk_column_sums(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, uint32_t *partial,
@@ -1503,8 +1539,8 @@ public:
     const unsigned tiles = cdiv(cols, 16);
     DevBuf<uint32_t> tl;
     tl.upload(syrk_tile_order(cols));
-    launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv(tiles * (tiles + 1) / 2, 8)), dim3(WG), stream_, (const uint32_t *)fx.p, cnt, (unsigned)rows,
-           cols, acc.p, as, (const uint32_t *)tl.p, (int)(tiles * (tiles + 1) / 2));
+    DevBuf<uint32_t> part;
+    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part);
     launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows);
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<uint32_t> a = acc.download();

@@ -85,6 +85,11 @@ inline hipError_t hipGetDeviceCount(int *n)
   return hipSuccess;
 }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d)
+{
+  *d = 0;
+  return hipSuccess;
+}
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
 {
   std::snprintf(p->name, sizeof p->name, "cpu-emulation");

@@ -26,8 +26,11 @@ def test_emulated_library_matches_reference_golden(name, limit):
     s.close()
 
 
-def test_emulated_int_syrk_is_exact():
+@pytest.mark.parametrize("splits", [None, "3"])
+def test_emulated_int_syrk_is_exact(splits, monkeypatch):
     import random
+    if splits:
+        monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", splits)  # row-split partial sums + k_syrk_reduce
     from oracle.oracle import Oracle
     sdp, meta, _, _ = parity.load_case("1d")
     s = SDPSolver(sdp, 128, lib_path=libs.emu_lib())  # NL=6 -> FX=4: |v| < 2^(32 FX - 3) = 2^125

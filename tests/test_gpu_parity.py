@@ -37,9 +37,12 @@ def test_device_arithmetic_matches_mpf(precision):
 
 
 # ---- the dominant kernel: fixed-point syrk is bit exact (integers)
-@pytest.mark.parametrize("precision,rows,cols", [(128, 37, 21), (512, 300, 50), (512, 9, 1), (1024, 64, 33)])
-def test_int_syrk_bit_exact(precision, rows, cols):
+@pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (512, 300, 50, None), (512, 9, 1, None),
+                                                        (1024, 64, 33, None), (512, 300, 50, "4"), (256, 100, 40, "16")])
+def test_int_syrk_bit_exact(precision, rows, cols, splits, monkeypatch):
     from oracle.oracle import Oracle
+    if splits:
+        monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", splits)  # row-split partial sums + k_syrk_reduce
     sdp, _, _, _ = parity.load_case("1d")
     s = _solver(sdp, precision)
     o = Oracle(sdp, precision)
