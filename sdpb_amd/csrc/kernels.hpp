@@ -32,6 +32,27 @@ template <int NL> MW_HD void mat_st(const Batch &b, const MatDesc &d, int i, int
   mw::store<NL>(b.p, (size_t)d.off + (size_t)i + (size_t)j * (size_t)d.ld, v);
 }
 
+// limb-major LDS image of STRIDE numbers (element idx of limb l at l*STRIDE + idx):
+// consecutive lanes reading consecutive elements hit distinct banks
+template <int NL, int STRIDE> MW_HD Mw<NL> smem_ld(const uint32_t *s, int idx)
+{
+  Mw<NL> v;
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    v.m[l] = s[l * STRIDE + idx];
+  v.e = (int32_t)s[NL * STRIDE + idx];
+  v.neg = s[(NL + 1) * STRIDE + idx];
+  return v;
+}
+template <int NL, int STRIDE> MW_HD void smem_st(uint32_t *s, int idx, const Mw<NL> &v)
+{
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    s[l * STRIDE + idx] = v.m[l];
+  s[NL * STRIDE + idx] = (uint32_t)v.e;
+  s[(NL + 1) * STRIDE + idx] = v.neg;
+}
+
 // ---------------------------------------------------------------------------
 // Generic element-wise and reduction drivers
 // ---------------------------------------------------------------------------
@@ -133,24 +154,8 @@ constexpr int CI_E = (PB * (PB - 1) / 2 + CI_D0 - 1) / CI_D0;         // off-dia
 static_assert(PB <= 64 && CI_E <= 3, "k_chol_inv_lds: element-to-lane mapping");
 
 // limb-major LDS image of a packed triangle (conflict-free for consecutive elements)
-template <int NL> MW_HD Mw<NL> ci_ld(const uint32_t *s, int idx)
-{
-  Mw<NL> v;
-#pragma unroll
-  for(int l = 0; l < NL; ++l)
-    v.m[l] = s[l * CI_NPK + idx];
-  v.e = (int32_t)s[NL * CI_NPK + idx];
-  v.neg = s[(NL + 1) * CI_NPK + idx];
-  return v;
-}
-template <int NL> MW_HD void ci_st(uint32_t *s, int idx, const Mw<NL> &v)
-{
-#pragma unroll
-  for(int l = 0; l < NL; ++l)
-    s[l * CI_NPK + idx] = v.m[l];
-  s[NL * CI_NPK + idx] = (uint32_t)v.e;
-  s[(NL + 1) * CI_NPK + idx] = v.neg;
-}
+template <int NL> MW_HD Mw<NL> ci_ld(const uint32_t *s, int idx) { return smem_ld<NL, CI_NPK>(s, idx); }
+template <int NL> MW_HD void ci_st(uint32_t *s, int idx, const Mw<NL> &v) { smem_st<NL, CI_NPK>(s, idx, v); }
 
 // One element (r,c), r > c, of a diagonal block, or a diagonal element (r == c).
 template <int NL> struct CiElem
@@ -401,8 +406,13 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
 //   T = X(:,panel p) - X(:,cols < k0) L(panel p, cols < k0)^T ;  X(:,panel p) = T Li_pp^T
 // One lane per (row, column of the panel); rows are the independent right-hand sides
 // (with B stored transposed this is schur_off_diagonal = L^{-1} B, compute_Q.cxx:48).
+// Both dot products run over chunks of KC columns whose operands — TR x KC numbers of X
+// (or of T) and PB x KC numbers of L (or of Li) — are fetched once per workgroup into
+// limb-major LDS tiles, so the inner loop is LDS reads + one Acc product per term.
+constexpr int TRSM_KC = PB < 8 ? PB : 8;
 template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p)
 {
+  constexpr int KC = TRSM_KC, SXN = TR * KC, SLN = PB * KC, STN = TR * PB;
   const int q = blockIdx.y;
   const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
   const int k0 = PB * p;
@@ -410,24 +420,58 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
     return;
   const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
   const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
-  const int r = blockIdx.x * TR + rl;
-  __shared__ Mw<NL> tile[TR][PB];
+  const int r0 = blockIdx.x * TR, r = r0 + rl;
+  __shared__ uint32_t sx[(NL + 2) * SXN], sl[(NL + 2) * SLN], st[(NL + 2) * STN];
   const bool ok = r < dx.rows && j < nb;
-  if(ok)
-    {
-      Acc<NL> acc = mw::acc_zero<NL>();
-      mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
-      for(int k = 0; k < k0; ++k)
-        mw::acc_fms(acc, mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k0 + j, k));
-      tile[rl][j] = mw::acc_result(acc);
-    }
-  __syncthreads();
-  if(!ok)
-    return;
   Acc<NL> acc = mw::acc_zero<NL>();
-  for(int j2 = 0; j2 <= j; ++j2)
-    mw::acc_fma(acc, tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2));
-  mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
+  if(ok)
+    mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
+  for(int k = 0; k < k0; k += KC) // k0 is a multiple of PB, PB of KC
+    {
+      for(int e = threadIdx.x; e < SXN + SLN; e += WG)
+        {
+          if(e < SXN)
+            {
+              const int kk = e / TR, rr = e % TR;
+              smem_st<NL, SXN>(sx, e, r0 + rr < dx.rows ? mat_ld<NL>(X, dx, r0 + rr, k + kk) : mw::zero<NL>());
+            }
+          else
+            {
+              const int f = e - SXN, kk = f / PB, jj = f % PB;
+              smem_st<NL, SLN>(sl, f, jj < nb ? mat_ld<NL>(L, dl, k0 + jj, k + kk) : mw::zero<NL>());
+            }
+        }
+      __syncthreads();
+      if(ok)
+        {
+#pragma unroll 1
+          for(int kk = 0; kk < KC; ++kk)
+            mw::acc_fms(acc, smem_ld<NL, SXN>(sx, kk * TR + rl), smem_ld<NL, SLN>(sl, kk * PB + j));
+        }
+      __syncthreads();
+    }
+  smem_st<NL, STN>(st, j * TR + rl, ok ? mw::acc_result(acc) : mw::zero<NL>());
+  acc = mw::acc_zero<NL>();
+  // X(r, k0+j) = sum_{j2 <= j} T(r, j2) Li(k0+j, k0+j2)
+  for(int c = 0; c < nb; c += KC)
+    {
+      for(int f = threadIdx.x; f < SLN; f += WG)
+        {
+          const int kk = f / PB, jj = f % PB;
+          smem_st<NL, SLN>(sl, f, (jj < nb && c + kk <= jj) ? mat_ld<NL>(Li, di, k0 + jj, k0 + c + kk) : mw::zero<NL>());
+        }
+      __syncthreads(); // also orders the writes of st before the first read
+      if(ok)
+        {
+#pragma unroll 1
+          for(int kk = 0; kk < KC; ++kk)
+            if(c + kk <= j)
+              mw::acc_fma(acc, smem_ld<NL, STN>(st, (c + kk) * TR + rl), smem_ld<NL, SLN>(sl, kk * PB + j));
+        }
+      __syncthreads();
+    }
+  if(ok)
+    mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
 }
 // X := X L^{-1}, panel p (backward over panels):
 //   T = X(:,panel p) - X(:,cols >= k0+nb) L(rows >= k0+nb, panel p) ;  X(:,panel p) = T Li_pp

@@ -200,12 +200,30 @@ MW_HD uint32_t clz32(uint32_t x)
 // (hi:lo) << c, upper word; 0 <= c <= 31
 MW_HD uint32_t funnel_l(uint32_t hi, uint32_t lo, uint32_t c)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return c ? __builtin_amdgcn_alignbit(hi, lo, 32u - c) : hi; // v_alignbit_b32
+#else
   return c ? ((hi << c) | (lo >> (32 - c))) : hi;
+#endif
 }
 // (hi:lo) >> c, lower word; 0 <= c <= 31
 MW_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t c)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, c); // one v_alignbit_b32; a shift of 0 returns lo
+#else
   return c ? ((lo >> c) | (hi << (32 - c))) : lo;
+#endif
+}
+// true if the predicate holds in any active lane of the wavefront: lets the log-step
+// shift networks skip the stages that no lane needs (the host build evaluates its own lane)
+MW_HD bool any_lane(bool p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(p) != 0;
+#else
+  return p;
+#endif
 }
 
 template <int NL> MW_HD Mw<NL> zero()
@@ -400,12 +418,15 @@ template <int NL> MW_HD Mw<NL> sqr(const Mw<NL> &a) { return mul(a, a); }
 
 // ---- addition / subtraction ------------------------------------------------
 // helpers on NL+1-limb working arrays (index NL = most significant)
-template <int W> MW_HD void shr_limbs(uint32_t (&x)[W], uint32_t q)
+template <int W, bool SKIP = false> MW_HD void shr_limbs(uint32_t (&x)[W], uint32_t q)
 {
 #pragma unroll
   for(int s = 1; s < W; s <<= 1)
     {
       const bool on = (q & (uint32_t)s) != 0;
+      if constexpr(SKIP) // most alignments are short: skip the stages no lane of the wavefront needs
+        if(!any_lane(on))
+          continue;
 #pragma unroll
       for(int i = 0; i < W; ++i)
         {
@@ -659,16 +680,17 @@ template <int NL> MW_HD void acc_add_raw(Acc<NL> &acc, const uint32_t (&P)[NL + 
   for(int i = 0; i <= NL; ++i)
     x[i] = P[i];
   x[NL + 1] = 0;
-  shr_limbs<NL + 2>(x, d >> 5);
+  shr_limbs<NL + 2, true>(x, d >> 5);
   shr_bits<NL + 2>(x, d & 31u);
+  // acc.w += negative ? -x : x  (two's complement: (x ^ mask) with the +1 as first carry)
   const uint32_t mask = 0u - negative;
-  uint32_t carry = negative;
+  Carry cy;
+  MW_CY_SET(cy, negative);
 #pragma unroll
   for(int i = 0; i < NL + 2; ++i)
     {
-      const uint64_t s = (uint64_t)acc.w[i] + (x[i] ^ mask) + carry;
-      acc.w[i] = (uint32_t)s;
-      carry = (uint32_t)(s >> 32);
+      const uint32_t t = x[i] ^ mask;
+      MW_ADDC(acc.w[i], t, cy);
     }
 }
 // acc += a*b (negate: acc -= a*b)
