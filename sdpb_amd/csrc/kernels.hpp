@@ -344,7 +344,8 @@ constexpr int TR = WG / PB;
 
 // Cholesky panel solve: A(r, panel p) := A(r, panel p) * Li_pp^T for the rows below the
 // diagonal block, and zero the part of the panel above it.   grid = (row tiles, batch)
-template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch A, Batch Li, int p)
+// row tiles [tile0, tile0 + gridDim.x) (the look-ahead schedule of Cholesky(Q) splits them)
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch A, Batch Li, int p, int tile0)
 {
   const int q = blockIdx.y;
   const MatDesc d = A.d[q], di = Li.d[q];
@@ -353,15 +354,16 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch
     return;
   const int nb = d.rows - k0 < PB ? d.rows - k0 : PB;
   const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
-  const int r = k0 + nb + blockIdx.x * TR + rl;
+  const int bx = (int)blockIdx.x + tile0;
+  const int r = k0 + nb + bx * TR + rl;
   __shared__ Mw<NL> tile[TR][PB];
   const bool ok = r < d.rows && j < nb;
-  if(blockIdx.x * TR >= d.rows - k0 - nb && blockIdx.x * TR >= k0)
+  if(bx * TR >= d.rows - k0 - nb && bx * TR >= k0)
     return;
   if(ok)
     tile[rl][j] = mat_ld<NL>(A, d, r, k0 + j);
   // rows above the diagonal block: upper triangle is zero in a lower factor
-  const int ru = blockIdx.x * TR + rl;
+  const int ru = bx * TR + rl;
   if(ru < k0 && j < nb)
     mat_st<NL>(A, d, ru, k0 + j, mw::zero<NL>());
   __syncthreads();
@@ -375,7 +377,8 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch
 
 // Trailing update of the blocked Cholesky: A22(i,j) -= sum_k A21(i,k) A21(j,k), i >= j,
 // with A21 = rows below panel p, columns of panel p.   grid = (lower tiles, batch)
-template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p)
+// lower tiles [tile0, tile0 + gridDim.x) of the trailing matrix
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p, int tile0)
 {
   const int q = blockIdx.y;
   const MatDesc d = A.d[q];
@@ -385,7 +388,7 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
   const int nb = d.rows - k0 < PB ? d.rows - k0 : PB;
   const int b0 = k0 + nb, M = d.rows - b0;
   const int tiles = (M + 15) / 16;
-  int tile = blockIdx.x;
+  int tile = (int)blockIdx.x + tile0;
   if(M <= 0 || tile >= tiles * (tiles + 1) / 2)
     return;
   int ti = 0;

@@ -210,7 +210,8 @@ template <int NL> class Solver : public SolverBase
   int terminate_reason_ = NotTerminated;
   Collectives coll_;
   hipStream_t stream_q_ = nullptr; // Cholesky(Q) runs here, concurrently with stream_
-  hipEvent_t ev_q_ready_ = nullptr, ev_q_done_ = nullptr;
+  hipEvent_t ev_q_ready_ = nullptr, ev_q_done_ = nullptr, ev_la_strip_ = nullptr, ev_la_bulk_ = nullptr;
+  hipStream_t stream_q2_ = nullptr; // bulk updates of the look-ahead Cholesky(Q)
   bool q_pending_ = false;
   hipEvent_t ev_syrk0_ = nullptr, ev_syrk1_ = nullptr;
   double syrk_kernel_ms_ = 0;
@@ -243,6 +244,9 @@ public:
     }
     HIP_CHECK(hipStreamCreate(&stream_));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_q_, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_q2_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_la_strip_, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_la_bulk_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&ev_q_ready_));
     HIP_CHECK(hipEventCreate(&ev_q_done_));
     HIP_CHECK(hipEventCreate(&ev_syrk0_));
@@ -256,6 +260,12 @@ public:
       (void)hipEventDestroy(ev_q_ready_);
     if(ev_q_done_)
       (void)hipEventDestroy(ev_q_done_);
+    if(ev_la_strip_)
+      (void)hipEventDestroy(ev_la_strip_);
+    if(ev_la_bulk_)
+      (void)hipEventDestroy(ev_la_bulk_);
+    if(stream_q2_)
+      (void)hipStreamDestroy(stream_q2_);
     if(stream_q_)
       (void)hipStreamDestroy(stream_q_);
     if(ev_syrk0_)
@@ -755,12 +765,48 @@ private:
         const int below = max_n - PB * (p + 1), above = PB * p;
         const int rows = std::max(below, above);
         if(rows > 0)
-          launch(k_chol_panel_solve<NL>, dim3(cdiv(rows, TR), A.count), dim3(WG), st, A, Li, p);
+          launch(k_chol_panel_solve<NL>, dim3(cdiv(rows, TR), A.count), dim3(WG), st, A, Li, p, 0);
         if(below > 0)
           {
             const unsigned tiles = cdiv(below, 16);
-            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), st, A, p);
+            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), st, A, p, 0);
           }
+      }
+  }
+  // The same factorisation of ONE matrix with a one-panel look-ahead on two streams: the
+  // diagonal block p+1 (a long dependent chain on a single CU) only needs the first PB
+  // rows of panel p and the leading PB x PB block of the trailing update, so those go
+  // first on `st`; the rest of panel p and of the update run on `st2` while block p+1 is
+  // being factored.  Entry: the work before is ordered on st; exit: everything is
+  // ordered on st.
+  void blocked_cholesky_lookahead(const Batch &A, const Batch &invd, const Batch &Li, int n, int *fail, hipStream_t st, hipStream_t st2)
+  {
+    const int panels = cdiv(n, PB);
+    constexpr int STRIP_ROW_TILES = PB / TR, STRIP_TILES = (PB / 16) * (PB / 16 + 1) / 2;
+    launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, 0, fail);
+    for(int p = 0; p < panels; ++p)
+      {
+        // here: diagonal block p is queued on st, and st has joined the bulk of step p-1
+        const int below = n - PB * (p + 1), above = PB * p;
+        const int row_tiles = cdiv(std::max(below, above), TR);
+        const unsigned tiles = below > 0 ? cdiv(below, 16) : 0;
+        const int ntile = (int)(tiles * (tiles + 1) / 2);
+        const int strip_rows = below > 0 ? std::min(row_tiles, STRIP_ROW_TILES) : 0;
+        const int strip_tiles = std::min(ntile, STRIP_TILES);
+        if(strip_rows > 0)
+          launch(k_chol_panel_solve<NL>, dim3(strip_rows, 1), dim3(WG), st, A, Li, p, 0);
+        HIP_CHECK(hipEventRecord(ev_la_strip_, st));
+        HIP_CHECK(hipStreamWaitEvent(st2, ev_la_strip_, 0));
+        if(row_tiles > strip_rows)
+          launch(k_chol_panel_solve<NL>, dim3(row_tiles - strip_rows, 1), dim3(WG), st2, A, Li, p, strip_rows);
+        if(ntile > strip_tiles)
+          launch(k_chol_syrk_down<NL>, dim3(ntile - strip_tiles, 1), dim3(WG), st2, A, p, strip_tiles);
+        HIP_CHECK(hipEventRecord(ev_la_bulk_, st2));
+        if(strip_tiles > 0)
+          launch(k_chol_syrk_down<NL>, dim3(strip_tiles, 1), dim3(WG), st, A, p, 0);
+        if(p + 1 < panels)
+          launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, p + 1, fail); // overlaps the bulk of step p
+        HIP_CHECK(hipStreamWaitEvent(st, ev_la_bulk_, 0));
       }
   }
   // X := X L^{-T} (rows of X are the right-hand sides)
@@ -1049,7 +1095,7 @@ private:
     int *qflags = flags_.p + 2 * std::max(Jl_, 1);
     HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
     HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
-    blocked_cholesky(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags, stream_q_);
+    blocked_cholesky_lookahead(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags, stream_q_, stream_q2_);
     HIP_CHECK(hipEventRecord(ev_q_done_, stream_q_));
     q_pending_ = true;
   }

@@ -156,6 +156,11 @@ inline hipError_t hipEventCreate(hipEvent_t *e)
   *e = new hipEmuEvent;
   return hipSuccess;
 }
+enum
+{
+  hipEventDisableTiming = 2
+};
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventDestroy(hipEvent_t e)
 {
   delete e;
