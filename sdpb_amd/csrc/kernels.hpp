@@ -341,12 +341,15 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
 // Tile helper shared by the panel kernels: a workgroup owns TR = 8 rows x PB columns;
 // lane t -> (row t % 8, column t / 8), so consecutive lanes read consecutive rows.
 constexpr int TR = WG / PB;
+constexpr int TRSM_KC = PB < 8 ? PB : 8; // columns per LDS-staged operand chunk of the panel kernels
 
 // Cholesky panel solve: A(r, panel p) := A(r, panel p) * Li_pp^T for the rows below the
 // diagonal block, and zero the part of the panel above it.   grid = (row tiles, batch)
-// row tiles [tile0, tile0 + gridDim.x) (the look-ahead schedule of Cholesky(Q) splits them)
+// row tiles [tile0, tile0 + gridDim.x) (the look-ahead schedule of Cholesky(Q) splits them).
+// The rows of the tile and chunks of KC columns of Li are staged in limb-major LDS.
 template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch A, Batch Li, int p, int tile0)
 {
+  constexpr int KC = TRSM_KC, SLN = PB * KC, STN = TR * PB;
   const int q = blockIdx.y;
   const MatDesc d = A.d[q], di = Li.d[q];
   const int k0 = PB * p;
@@ -356,30 +359,46 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch
   const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
   const int bx = (int)blockIdx.x + tile0;
   const int r = k0 + nb + bx * TR + rl;
-  __shared__ Mw<NL> tile[TR][PB];
+  __shared__ uint32_t sl[(NL + 2) * SLN], st[(NL + 2) * STN];
   const bool ok = r < d.rows && j < nb;
   if(bx * TR >= d.rows - k0 - nb && bx * TR >= k0)
     return;
-  if(ok)
-    tile[rl][j] = mat_ld<NL>(A, d, r, k0 + j);
+  smem_st<NL, STN>(st, j * TR + rl, ok ? mat_ld<NL>(A, d, r, k0 + j) : mw::zero<NL>());
   // rows above the diagonal block: upper triangle is zero in a lower factor
   const int ru = bx * TR + rl;
   if(ru < k0 && j < nb)
     mat_st<NL>(A, d, ru, k0 + j, mw::zero<NL>());
-  __syncthreads();
-  if(!ok)
+  if(bx * TR >= d.rows - k0 - nb) // nothing below the diagonal block in this tile (uniform)
     return;
   Acc<NL> acc = mw::acc_zero<NL>();
-  for(int j2 = 0; j2 <= j; ++j2)
-    mw::acc_fma(acc, tile[rl][j2], mat_ld<NL>(Li, di, k0 + j, k0 + j2));
-  mat_st<NL>(A, d, r, k0 + j, mw::acc_result(acc));
+  for(int c = 0; c < nb; c += KC)
+    {
+      for(int f = threadIdx.x; f < SLN; f += WG)
+        {
+          const int kk = f / PB, jj = f % PB;
+          smem_st<NL, SLN>(sl, f, (jj < nb && c + kk <= jj) ? mat_ld<NL>(Li, di, k0 + jj, k0 + c + kk) : mw::zero<NL>());
+        }
+      __syncthreads();
+      if(ok)
+        {
+#pragma unroll 1
+          for(int kk = 0; kk < KC; ++kk)
+            if(c + kk <= j)
+              mw::acc_fma(acc, smem_ld<NL, STN>(st, (c + kk) * TR + rl), smem_ld<NL, SLN>(sl, kk * PB + j));
+        }
+      __syncthreads();
+    }
+  if(ok)
+    mat_st<NL>(A, d, r, k0 + j, mw::acc_result(acc));
 }
 
 // Trailing update of the blocked Cholesky: A22(i,j) -= sum_k A21(i,k) A21(j,k), i >= j,
 // with A21 = rows below panel p, columns of panel p.   grid = (lower tiles, batch)
-// lower tiles [tile0, tile0 + gridDim.x) of the trailing matrix
+// lower tiles [tile0, tile0 + gridDim.x) of the trailing matrix; the two 16 x KC operand
+// chunks of a tile are staged in limb-major LDS
 template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p, int tile0)
 {
+  constexpr int KC = TRSM_KC, SN = 16 * KC;
   const int q = blockIdx.y;
   const MatDesc d = A.d[q];
   const int k0 = PB * p;
@@ -395,14 +414,32 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
   while((ti + 1) * (ti + 2) / 2 <= tile)
     ++ti;
   const int tj = tile - ti * (ti + 1) / 2;
-  const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
-  if(i >= M || j > i)
-    return;
+  const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
+  const int i = ti * 16 + li, j = tj * 16 + lj;
+  const bool ok = i < M && j <= i;
+  __shared__ uint32_t sa[(NL + 2) * SN], sb[(NL + 2) * SN];
   Acc<NL> acc = mw::acc_zero<NL>();
-  mw::acc_add(acc, mat_ld<NL>(A, d, b0 + i, b0 + j));
-  for(int k = 0; k < nb; ++k)
-    mw::acc_fms(acc, mat_ld<NL>(A, d, b0 + i, k0 + k), mat_ld<NL>(A, d, b0 + j, k0 + k));
-  mat_st<NL>(A, d, b0 + i, b0 + j, mw::acc_result(acc));
+  if(ok)
+    mw::acc_add(acc, mat_ld<NL>(A, d, b0 + i, b0 + j));
+  for(int c = 0; c < nb; c += KC)
+    {
+      for(int e = threadIdx.x; e < 2 * SN; e += WG)
+        {
+          const int f = e % SN, kk = f / 16, rr = f % 16;
+          const int row = (e < SN ? ti : tj) * 16 + rr;
+          smem_st<NL, SN>(e < SN ? sa : sb, f, (row < M && c + kk < nb) ? mat_ld<NL>(A, d, b0 + row, k0 + c + kk) : mw::zero<NL>());
+        }
+      __syncthreads();
+      if(ok)
+        {
+#pragma unroll 1
+          for(int kk = 0; kk < KC; ++kk)
+            mw::acc_fms(acc, smem_ld<NL, SN>(sa, kk * 16 + li), smem_ld<NL, SN>(sb, kk * 16 + lj));
+        }
+      __syncthreads();
+    }
+  if(ok)
+    mat_st<NL>(A, d, b0 + i, b0 + j, mw::acc_result(acc));
 }
 
 // X := X L^{-T}, panel p (forward over panels):
@@ -412,7 +449,6 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
 // Both dot products run over chunks of KC columns whose operands — TR x KC numbers of X
 // (or of T) and PB x KC numbers of L (or of Li) — are fetched once per workgroup into
 // limb-major LDS tiles, so the inner loop is LDS reads + one Acc product per term.
-constexpr int TRSM_KC = PB < 8 ? PB : 8;
 template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p)
 {
   constexpr int KC = TRSM_KC, SXN = TR * KC, SLN = PB * KC, STN = TR * PB;
