@@ -154,6 +154,8 @@ def main():
         stages = {k: round((timers1[k] - timers0.get(k, 0.0)) / args.steps, 3) for k in timers1
                   if not k.startswith("kernel.")}
         nl = solver.limbs
+        from sdpb_amd.solver import copy_bandwidth_gbs
+        copy_gbs = copy_bandwidth_gbs(1 << 30, 5)
         out = {
             "metric": "interior-point iterations/sec at --precision 512",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -166,6 +168,7 @@ def main():
                        "parallelism": f"blocks sharded over {world} GPU(s); Q' summed by integer all-reduce"},
             "roofline": {"bound": "hbm", "kernel": "k_syrk_fx", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_peak": copy_gbs,
                          "launch_ms": 1000.0 * k_avg_s, "algorithmic_bytes_per_launch": k_bytes,
                          "limb_mac_per_s": k_macs / k_avg_s if k_avg_s > 0 else 0.0,
                          "limb_mac_frac_of_measured_valu_peak": (k_macs / k_avg_s / LIMB_MAC_PEAK) if k_avg_s > 0 else 0.0},

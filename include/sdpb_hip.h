@@ -142,6 +142,12 @@ int sdpb_hip_op_int_syrk(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, c
 int sdpb_hip_host_encode_u64(const char *decimal_integer, int planes, unsigned long long *lanes);
 int sdpb_hip_host_decode_u64(const unsigned long long *lanes, int planes, char *buf, size_t buflen, size_t *needed);
 
+/* Measured HBM ceiling of the device the caller has selected: a streaming copy of `bytes`
+ * (read + write counted) repeated `reps` times by a plain 16-byte-per-lane kernel; the
+ * best repetition in GB/s.  bench.py reports it next to the 8 TB/s data-sheet peak
+ * (SURVEY.md section 8d asks for a measured copy ceiling). */
+int sdpb_hip_copy_bandwidth(size_t bytes, int reps, double *gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,17 @@ int copy_out(sdpb_hip_ctx *ctx, const std::string &s, char *buf, size_t buflen, 
 }
 } // namespace
 
+// streaming copy, 16 bytes per lane (sdpb_hip_copy_bandwidth: the measured HBM ceiling)
+struct alignas(16) Quad
+{
+  uint32_t x, y, z, w;
+};
+__global__ void __launch_bounds__(256) k_copy16(const Quad *src, Quad *dst, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dst[i] = src[i];
+}
+
 extern "C" {
 
 int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
@@ -316,5 +327,39 @@ int sdpb_hip_host_decode_u64(const unsigned long long *lanes, int planes, char *
     return 4;
   std::memcpy(buf, out.c_str(), out.size() + 1);
   return 0;
+}
+int sdpb_hip_copy_bandwidth(size_t bytes, int reps, double *gb_per_s)
+{
+  try
+    {
+      const size_t n = std::max<size_t>(bytes / 16, 1);
+      sdpb::DevBuf<Quad> src, dst;
+      src.alloc(n);
+      dst.alloc(n);
+      hipEvent_t e0, e1;
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      double best = 0;
+      for(int r = 0; r < std::max(reps, 1) + 1; ++r)
+        {
+          HIP_CHECK(hipEventRecord(e0, nullptr));
+          hipLaunchKernelGGL(k_copy16, dim3(256 * 32), dim3(256), 0, nullptr, (const Quad *)src.p, dst.p, n);
+          HIP_CHECK(hipEventRecord(e1, nullptr));
+          HIP_CHECK(hipEventSynchronize(e1));
+          float ms = 0;
+          HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+          if(r > 0 && ms > 0) // repetition 0 warms up
+            best = std::max(best, 2.0 * 16.0 * (double)n / (ms * 1e-3) / 1e9);
+        }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      *gb_per_s = best;
+      return 0;
+    }
+  catch(const std::exception &e)
+    {
+      g_create_error = e.what();
+      return 3;
+    }
 }
 } // extern "C"

@@ -44,6 +44,8 @@ def _options(argv: Optional[List[str]] = None):
     for flag in ("findPrimalFeasible", "findDualFeasible", "detectPrimalFeasibleJump", "detectDualFeasibleJump"):
         ap.add_argument("--" + flag, action="store_true")
     ap.add_argument("--writeSolution", default="x,y", help="comma separated subset of x,y,X,Y,z")
+    ap.add_argument("-i", "--initialCheckpointDir", default=None,
+                    help="text checkpoint: a directory written with --writeSolution=x,y,X,Y (load_text_checkpoint.cxx:6-44)")
     ap.add_argument("--verbosity", type=int, default=1)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--noFinalCheckpoint", action="store_true", help="accepted for compatibility")
@@ -114,6 +116,27 @@ def _z_from_y(y: List[str], normalization: List[str], precision: int) -> List[st
         return [mpmath.nstr(v, _digits(precision), strip_zeros=False) for v in z]
 
 
+def _read_numbers(path: str, rows: int, cols: int) -> List[str]:
+    with open(path) as f:
+        tok = f.read().split()
+    if int(tok[0]) != rows or int(tok[1]) != cols or len(tok) != 2 + rows * cols:
+        raise ValueError(f"{path}: expected a {rows} x {cols} block")
+    return tok[2:]
+
+
+def load_text_checkpoint(solver: SDPSolver, sdp, directory: str):
+    """x_<j>.txt, y.txt, X_matrix_<q>.txt, Y_matrix_<q>.txt -> solver state (load_text_checkpoint.cxx:6-44)."""
+    solver.set_array("y", _read_numbers(os.path.join(directory, "y.txt"), sdp.N, 1))
+    for j, blk in enumerate(sdp.blocks):
+        solver.set_array("x", _read_numbers(os.path.join(directory, f"x_{j}.txt"), blk.schur_size, 1), j)
+        for parity, n in enumerate(blk.psd_sizes):
+            if n == 0:
+                continue
+            for name in ("X", "Y"):
+                rowmajor = _read_numbers(os.path.join(directory, f"{name}_matrix_{2 * j + parity}.txt"), n, n)
+                solver.set_array(name, [rowmajor[i * n + jj] for jj in range(n) for i in range(n)], j, parity)
+
+
 def solve(argv: Optional[List[str]] = None) -> str:
     o = _options(argv)
     out_dir = o.outDir or (o.sdpDir.rstrip("/") + "_out")
@@ -126,6 +149,8 @@ def solve(argv: Optional[List[str]] = None) -> str:
                   detectDualFeasibleJump=int(o.detectDualFeasibleJump))
     start = time.time()
     solver = SDPSolver(sdp, o.precision, params, device=o.device, lib_path=o.lib)
+    if o.initialCheckpointDir:
+        load_text_checkpoint(solver, sdp, o.initialCheckpointDir)
     if o.verbosity >= 1:
         print(f"Initialize SDP solver\n\tprimal dimension: {sdp.P_total}\n\tdual dimension: {sdp.N}"
               f"\n\tSDP blocks: {sdp.J}")

@@ -105,6 +105,17 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     return L
 
 
+def copy_bandwidth_gbs(nbytes: int = 1 << 30, reps: int = 5, lib_path: Optional[str] = None) -> float:
+    """Measured streaming-copy rate (read + write) of the current device in GB/s (sdpb_hip_copy_bandwidth)."""
+    L = load_library(lib_path)
+    out = ctypes.c_double(0.0)
+    L.sdpb_hip_copy_bandwidth.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    rc = L.sdpb_hip_copy_bandwidth(nbytes, reps, ctypes.byref(out))
+    if rc:
+        raise SDPBError(rc, L.sdpb_hip_last_error(None).decode())
+    return out.value
+
+
 def plan_blocks(dims: List[int], num_points: List[int], N: int, world_size: int,
                 lib_path: Optional[str] = None) -> List[int]:
     """Block -> rank assignment (pure host logic, no GPU needed)."""

@@ -79,6 +79,32 @@ def test_driver_writes_sdpb_result_files_emulated(tmp_path):
     assert n == m == len(rows) and all(len(r) == n for r in rows)
 
 
+def test_text_checkpoint_restart_continues_the_same_trajectory(tmp_path):
+    """--writeSolution=x,y,X,Y then -i <dir>: 3 + 3 iterations equal 6 iterations
+    up to the decimal round trip of the checkpoint files."""
+    lib = libs.emu_lib()
+    base = _argv("1d-constraints", str(tmp_path / "full"), lib)
+    it = base.index("--maxIterations") if "--maxIterations" in base else None
+    def with_max(argv, n):
+        argv = list(argv)
+        if "--maxIterations" in argv:
+            k = argv.index("--maxIterations")
+            del argv[k:k + 2]
+        return argv + ["--maxIterations", str(n)]
+    run.solve(with_max(base, 6))
+    first = with_max(_argv("1d-constraints", str(tmp_path / "a"), lib), 3)
+    run.solve(first)
+    second = with_max(_argv("1d-constraints", str(tmp_path / "b"), lib), 3) + ["-i", str(tmp_path / "a")]
+    run.solve(second)
+    with open(tmp_path / "full" / "iterations.json") as f:
+        full = json.load(f)
+    with open(tmp_path / "b" / "iterations.json") as f:
+        cont = json.load(f)
+    for g, w in zip(cont, full[3:6]):
+        bad, _ = parity.compare_iteration(g, w, tol_bits=600)
+        assert not bad, bad
+
+
 def test_options_are_parsed_like_sdpb_parses_them():
     """64-bit GMP parse (SDPB_Parameters.cxx runs before El::gmp::SetPrecision): compare with real GMP."""
     from fractions import Fraction
