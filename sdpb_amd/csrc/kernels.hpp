@@ -150,8 +150,13 @@ constexpr int PB = SDPB_PB; // panel width (tests also build a PB = 4 variant to
 constexpr int CI_T = 256;      // lanes of the diagonal-block kernel: one wavefront per SIMD of a CU
 constexpr int CI_D0 = CI_T - 64; // first lane of the wavefront that owns the diagonal
 constexpr int CI_NPK = PB * (PB + 1) / 2;                             // packed lower triangle (LDS images)
-constexpr int CI_E = (PB * (PB - 1) / 2 + CI_D0 - 1) / CI_D0;         // off-diagonal elements per lane
-static_assert(PB <= 64 && CI_E <= 3, "k_chol_inv_lds: element-to-lane mapping");
+// Off-diagonal elements are dealt to lanes as a round-robin tournament: round m (PB-1 of
+// them) pairs up all PB indices, and a lane takes up to three pairs of ONE round, so the
+// (up to three) elements of a lane never share a row or column index — at every pivot k
+// a lane finishes at most one element of column k / row k.
+constexpr int CI_E = 3;                                 // off-diagonal elements per lane
+constexpr int CI_GPR = (PB / 2 + CI_E - 1) / CI_E;      // lanes per round
+static_assert(PB % 2 == 0 && PB <= 64 && (PB - 1) * CI_GPR <= CI_D0, "k_chol_inv_lds: element-to-lane mapping");
 
 // limb-major LDS image of a packed triangle (conflict-free for consecutive elements)
 template <int NL> MW_HD Mw<NL> ci_ld(const uint32_t *s, int idx) { return smem_ld<NL, CI_NPK>(s, idx); }
@@ -164,20 +169,27 @@ template <int NL> struct CiElem
   Acc<NL> acc;
 };
 #define SDPB_PK(r, c) ((c) * n - (c) * ((c)-1) / 2 + ((r) - (c)))
-// element number idx of the strictly lower triangle, column by column
-template <int NL> MW_HD void ci_init_offdiag(CiElem<NL> &el, int idx, int n, const Batch &A, const MatDesc &d, int k0)
+// pair number i of round m of the tournament on PB players (circle method); the element is
+// dropped when one of its indices lies outside the n x n block
+template <int NL> MW_HD void ci_init_offdiag(CiElem<NL> &el, int m, int i, int n, const Batch &A, const MatDesc &d, int k0)
 {
-  int c = 0, off = 0;
-  while(c < n - 2 && off + (n - 1 - c) <= idx)
+  int a, b;
+  if(i == 0)
     {
-      off += n - 1 - c;
-      ++c;
+      a = PB - 1;
+      b = m;
     }
-  el.c = c;
-  el.r = idx < n * (n - 1) / 2 ? c + 1 + (idx - off) : -1;
+  else
+    {
+      a = (m + i) % (PB - 1);
+      b = (m - i + (PB - 1)) % (PB - 1);
+    }
+  const bool valid = m < PB - 1 && i < PB / 2 && a < n && b < n;
+  el.r = valid ? (a > b ? a : b) : -1;
+  el.c = valid ? (a > b ? b : a) : 0;
   el.acc = mw::acc_zero<NL>();
-  if(el.r >= 0)
-    mw::acc_add(el.acc, mat_ld<NL>(A, d, k0 + el.r, k0 + c));
+  if(valid)
+    mw::acc_add(el.acc, mat_ld<NL>(A, d, k0 + el.r, k0 + el.c));
 }
 // (2) finish column k of L and row k of X:  L(r,k) = acc / L_kk,  X(k,c) = -acc / L_kk
 template <int NL> MW_HD void ci_finish(CiElem<NL> &el, int k, int n, uint32_t *sL, uint32_t *sX, const uint32_t *s_inv)
@@ -250,11 +262,10 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
     }
   else
     {
-      ci_init_offdiag<NL>(e0, t, n, A, d, k0);
-      if constexpr(CI_E > 1)
-        ci_init_offdiag<NL>(e1, t + CI_D0, n, A, d, k0);
-      if constexpr(CI_E > 2)
-        ci_init_offdiag<NL>(e2, t + 2 * CI_D0, n, A, d, k0);
+      const int m = t / CI_GPR, g = t % CI_GPR;
+      ci_init_offdiag<NL>(e0, m, CI_E * g, n, A, d, k0);
+      ci_init_offdiag<NL>(e1, m, CI_E * g + 1, n, A, d, k0);
+      ci_init_offdiag<NL>(e2, m, CI_E * g + 2, n, A, d, k0);
     }
   if(t == 0)
     s_fail = 0;
@@ -303,11 +314,21 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
         }
       else
         {
-          ci_finish<NL>(e0, k, n, sL, sX, s_inv);
-          if constexpr(CI_E > 1)
-            ci_finish<NL>(e1, k, n, sL, sX, s_inv);
-          if constexpr(CI_E > 2)
-            ci_finish<NL>(e2, k, n, sL, sX, s_inv);
+          // at most one of the lane's elements lies in column k or row k: pick it, finish it once
+          const bool m0 = e0.r >= 0 && (e0.r == k || e0.c == k) && e0.r >= k;
+          const bool m1 = e1.r >= 0 && (e1.r == k || e1.c == k) && e1.r >= k;
+          const bool m2 = e2.r >= 0 && (e2.r == k || e2.c == k) && e2.r >= k;
+          if(m0 || m1 || m2)
+            {
+              CiElem<NL> sel = m0 ? e0 : (m1 ? e1 : e2);
+              ci_finish<NL>(sel, k, n, sL, sX, s_inv);
+              if(m0)
+                e0.acc = sel.acc;
+              else if(m1)
+                e1.acc = sel.acc;
+              else
+                e2.acc = sel.acc;
+            }
         }
       __syncthreads();
       // (3) one product per element below row k
@@ -322,10 +343,8 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
       else
         {
           ci_update<NL>(e0, k, n, sL, sX);
-          if constexpr(CI_E > 1)
-            ci_update<NL>(e1, k, n, sL, sX);
-          if constexpr(CI_E > 2)
-            ci_update<NL>(e2, k, n, sL, sX);
+          ci_update<NL>(e1, k, n, sL, sX);
+          ci_update<NL>(e2, k, n, sL, sX);
         }
     }
   __syncthreads();
