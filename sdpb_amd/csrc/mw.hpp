@@ -826,13 +826,18 @@ template <> struct RcpMant<1>
   static MW_HD Mw<1> run(const Mw<1> &man) { return from_double<1>(1.0 / to_double(man)); }
 };
 
+template <int NL> MW_HD Mw<NL> rcp_mant_fx(const Mw<NL> &man); // fixed-point Newton, below
 template <int NL> MW_HD Mw<NL> rcp(const Mw<NL> &a)
 {
   // caller guarantees a != 0
   Mw<NL> man = a;
   man.e = 0;
   man.neg = 0;
-  Mw<NL> r = RcpMant<NL>::run(man);
+  Mw<NL> r;
+  if constexpr(NL >= 4)
+    r = rcp_mant_fx<NL>(man);
+  else
+    r = RcpMant<NL>::run(man);
   r.e -= a.e;
   r.neg = a.neg;
   return r;
@@ -893,6 +898,235 @@ template <> struct RsqrtMant<1>
   static MW_HD Mw<1> run(const Mw<1> &man) { return from_double<1>(1.0 / host_device_sqrt(to_double(man))); }
 };
 
+// ---- fixed-point Newton for the inverse square root -----------------------------
+// The Mw iteration above spends most of its time aligning and normalising (an `add` costs
+// as much as a `mul`).  Here every quantity has a compile-time binary point, so a level is
+// two integer products + one more at half width and two carry chains, and the half-width
+// iterate is never padded to full width:
+//   y' = y + y (1 - x y^2)/2,   X, Y in "Q2" fixed point: value = limbs / 2^(32 L - 2).
+// limbs [F, LA+LB) of a*b by product scanning; columns below F-2 are dropped (< 2^-26 of limb F)
+template <int LA, int LB, int F, int K> struct FxColumns
+{
+  static MW_HD void run(const uint32_t (&a)[LA], const uint32_t (&b)[LB], uint64_t &lo, uint32_t &hi, uint32_t (&out)[LA + LB - F])
+  {
+    constexpr int I0 = K - (LB - 1) > 0 ? K - (LB - 1) : 0, I1 = K < LA - 1 ? K : LA - 1;
+    mac_column<I0, I1, K>(lo, hi, a, b);
+    if constexpr(K >= F)
+      out[K - F] = (uint32_t)lo;
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+    if constexpr(K < LA + LB - 2)
+      FxColumns<LA, LB, F, K + 1>::run(a, b, lo, hi, out);
+    else
+      out[LA + LB - 1 - F] = (uint32_t)lo;
+  }
+};
+template <int LA, int LB, int F> MW_HD void fx_mul_from(const uint32_t (&a)[LA], const uint32_t (&b)[LB], uint32_t (&out)[LA + LB - F])
+{
+  constexpr int K0 = F - 2 > 0 ? F - 2 : 0;
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+  FxColumns<LA, LB, F, K0>::run(a, b, lo, hi, out);
+}
+// Y (L limbs, Q2) ~ 1/sqrt(x), x in [0.5, 2) given as X (NX limbs, Q2); error < 2^-(32L-8)
+template <int NX, int L> struct RsqrtFx
+{
+  static MW_HD void run(const uint32_t (&X)[NX], uint32_t (&Y)[L])
+  {
+    if constexpr(L <= 2)
+      {
+        static_assert(L == 2, "seed width");
+        const uint64_t xt = ((uint64_t)X[NX - 1] << 32) | X[NX - 2];
+        const double xd = (double)xt * (1.0 / 4611686018427387904.0); // 2^-62
+        const uint64_t y = (uint64_t)((1.0 / host_device_sqrt(xd)) * 4611686018427387904.0);
+        Y[0] = (uint32_t)y;
+        Y[1] = (uint32_t)(y >> 32);
+      }
+    else
+      {
+        constexpr int H = L / 2 + 1, T = L + 1 + 2 * H, LO = L + 3, LD = L - H + 4;
+        static_assert(NX >= L + 1, "x needs one guard limb");
+        uint32_t Yh[H];
+        RsqrtFx<NX, H>::run(X, Yh);
+        uint32_t S[2 * H]; // y^2 exactly, value = S / 2^(64H - 4)
+        fx_mul_from<H, H, 0>(Yh, Yh, S);
+        uint32_t Xs[L + 1];
+#pragma unroll
+        for(int i = 0; i <= L; ++i)
+          Xs[i] = X[NX - (L + 1) + i];
+        uint32_t D[LO]; // x y^2 with 1.0 = 2^(32 LO - 6)
+        fx_mul_from<L + 1, 2 * H, T - LO>(Xs, S, D);
+        // D <- 1 - x y^2 (two's complement), then sign + magnitude
+        uint64_t bw = 0;
+#pragma unroll
+        for(int i = 0; i < LO; ++i)
+          {
+            const uint64_t one = (i == LO - 1) ? 0x04000000u : 0u;
+            const uint64_t d = one - (uint64_t)D[i] - bw;
+            D[i] = (uint32_t)d;
+            bw = (d >> 63) & 1u;
+          }
+        const uint32_t negative = D[LO - 1] >> 31, mask = 0u - negative;
+        uint64_t cy = negative;
+        uint32_t Dm[LD]; // |1 - x y^2| < 2^-(32H-8): its limbs above LD are zero
+#pragma unroll
+        for(int i = 0; i < LD; ++i)
+          {
+            const uint64_t t = (uint64_t)(D[i] ^ mask) + cy;
+            Dm[i] = (uint32_t)t;
+            cy = t >> 32;
+          }
+        // y |D| / 2 at Y's scale: product limbs [H+2, H+LD) shifted left by 5 bits
+        uint32_t Pm[LD - 2];
+        fx_mul_from<H, LD, H + 2>(Yh, Dm, Pm);
+        // Y = Yh 2^(32(L-H)) +/- C
+        uint64_t c = 0;
+#pragma unroll
+        for(int i = 0; i < L; ++i)
+          {
+            const uint32_t base = i >= L - H ? Yh[i >= L - H ? i - (L - H) : 0] : 0u;
+            uint32_t corr = 0;
+            if(i <= L - H)
+              corr = (Pm[i + 1 < LD - 2 ? i + 1 : LD - 3] << 5) | (Pm[i] >> 27);
+            if(negative)
+              {
+                const uint64_t t = (uint64_t)base - corr - c;
+                Y[i] = (uint32_t)t;
+                c = (t >> 63) & 1u;
+              }
+            else
+              {
+                const uint64_t t = (uint64_t)base + corr + c;
+                Y[i] = (uint32_t)t;
+                c = t >> 32;
+              }
+          }
+      }
+  }
+};
+// 1/sqrt(man) for man in [0.5,2) (e in {0,1}, positive)
+template <int NL> MW_HD Mw<NL> rsqrt_mant_fx(const Mw<NL> &man)
+{
+  constexpr int NX = NL + 2, L = NL + 1;
+  uint32_t X[NX]; // x 2^(32 NX - 2) = M 2^(62 + e)
+  const uint32_t sh = 2u - (uint32_t)man.e;
+#pragma unroll
+  for(int i = 0; i < NX; ++i)
+    {
+      const uint32_t lo = (i >= 2) ? man.m[i >= 2 ? i - 2 : 0] : 0u;
+      const uint32_t up = (i >= 1 && i - 1 < NL) ? man.m[(i >= 1 && i - 1 < NL) ? i - 1 : 0] : 0u;
+      X[i] = (lo >> sh) | (up << (32u - sh));
+    }
+  uint32_t Y[L];
+  RsqrtFx<NX, L>::run(X, Y);
+  const uint32_t ge1 = (Y[L - 1] >> 30) & 1u, shy = 30u + ge1;
+  Mw<NL> r;
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    r.m[i] = (Y[i] >> shy) | (Y[i + 1] << (32u - shy));
+  r.e = (int32_t)ge1;
+  r.neg = 0;
+  return r;
+}
+
+// The reciprocal the same way: y' = y + y (1 - x y), x in [0.5, 1), y in (1, 2], both Q2.
+template <int NX, int L> struct RcpFx
+{
+  static MW_HD void run(const uint32_t (&X)[NX], uint32_t (&Y)[L])
+  {
+    if constexpr(L <= 2)
+      {
+        static_assert(L == 2, "seed width");
+        const uint64_t xt = ((uint64_t)X[NX - 1] << 32) | X[NX - 2];
+        const double xd = (double)xt * (1.0 / 4611686018427387904.0); // 2^-62
+        double yd = (1.0 / xd) * 4611686018427387904.0;
+        if(yd > 9223372036854775808.0)
+          yd = 9223372036854775808.0; // y <= 2
+        const uint64_t y = yd >= 9223372036854775808.0 ? 0x8000000000000000ull : (uint64_t)yd;
+        Y[0] = (uint32_t)y;
+        Y[1] = (uint32_t)(y >> 32);
+      }
+    else
+      {
+        constexpr int H = L / 2 + 1, T = L + 1 + H, LO = L + 3, LD = L - H + 4;
+        static_assert(NX >= L + 1 && T >= LO, "x needs one guard limb");
+        uint32_t Yh[H];
+        RcpFx<NX, H>::run(X, Yh);
+        uint32_t Xs[L + 1];
+#pragma unroll
+        for(int i = 0; i <= L; ++i)
+          Xs[i] = X[NX - (L + 1) + i];
+        uint32_t D[LO]; // x y with 1.0 = 2^(32 LO - 4)
+        fx_mul_from<L + 1, H, T - LO>(Xs, Yh, D);
+        uint64_t bw = 0;
+#pragma unroll
+        for(int i = 0; i < LO; ++i)
+          {
+            const uint64_t one = (i == LO - 1) ? 0x10000000u : 0u;
+            const uint64_t d = one - (uint64_t)D[i] - bw;
+            D[i] = (uint32_t)d;
+            bw = (d >> 63) & 1u;
+          }
+        const uint32_t negative = D[LO - 1] >> 31, mask = 0u - negative;
+        uint64_t cy = negative;
+        uint32_t Dm[LD];
+#pragma unroll
+        for(int i = 0; i < LD; ++i)
+          {
+            const uint64_t t = (uint64_t)(D[i] ^ mask) + cy;
+            Dm[i] = (uint32_t)t;
+            cy = t >> 32;
+          }
+        uint32_t Pm[LD - 2]; // y |D| at Y's scale: product limbs [H+2, H+LD) shifted left by 4 bits
+        fx_mul_from<H, LD, H + 2>(Yh, Dm, Pm);
+        uint64_t c = 0;
+#pragma unroll
+        for(int i = 0; i < L; ++i)
+          {
+            const uint32_t base = i >= L - H ? Yh[i >= L - H ? i - (L - H) : 0] : 0u;
+            uint32_t corr = 0;
+            if(i <= L - H)
+              corr = (Pm[i + 1 < LD - 2 ? i + 1 : LD - 3] << 4) | (Pm[i] >> 28);
+            if(negative)
+              {
+                const uint64_t t = (uint64_t)base - corr - c;
+                Y[i] = (uint32_t)t;
+                c = (t >> 63) & 1u;
+              }
+            else
+              {
+                const uint64_t t = (uint64_t)base + corr + c;
+                Y[i] = (uint32_t)t;
+                c = t >> 32;
+              }
+          }
+      }
+  }
+};
+// 1/man for man in [0.5,1) (e = 0, positive)
+template <int NL> MW_HD Mw<NL> rcp_mant_fx(const Mw<NL> &man)
+{
+  constexpr int NX = NL + 2, L = NL + 1;
+  uint32_t X[NX]; // x 2^(32 NX - 2) = M 2^62
+#pragma unroll
+  for(int i = 0; i < NX; ++i)
+    {
+      const uint32_t lo = (i >= 2) ? man.m[i >= 2 ? i - 2 : 0] : 0u;
+      const uint32_t up = (i >= 1 && i - 1 < NL) ? man.m[(i >= 1 && i - 1 < NL) ? i - 1 : 0] : 0u;
+      X[i] = (lo >> 2) | (up << 30);
+    }
+  uint32_t Y[L];
+  RcpFx<NX, L>::run(X, Y);
+  const uint32_t two = Y[L - 1] >> 31; // y == 2 (x == 1/2)
+  Mw<NL> r;
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    r.m[i] = two ? Y[i + 1] : ((Y[i] >> 31) | (Y[i + 1] << 1));
+  r.e = 1 + (int32_t)two;
+  r.neg = 0;
+  return r;
+}
+
 // 1/sqrt(a), a > 0
 template <int NL> MW_HD Mw<NL> rsqrt(const Mw<NL> &a)
 {
@@ -902,7 +1136,11 @@ template <int NL> MW_HD Mw<NL> rsqrt(const Mw<NL> &a)
   man.e = odd;
   man.neg = 0;
   e -= odd;
-  Mw<NL> r = RsqrtMant<NL>::run(man);
+  Mw<NL> r;
+  if constexpr(NL >= 4)
+    r = rsqrt_mant_fx<NL>(man);
+  else
+    r = RsqrtMant<NL>::run(man);
   r.e -= e / 2;
   return r;
 }
