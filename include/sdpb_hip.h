@@ -91,7 +91,7 @@ int sdpb_hip_get_scalar(sdpb_hip_ctx *ctx, const char *name, char *buf, size_t b
 
 /* Solver state and work arrays, column-major, one decimal per line.  which: x X y Y
  * (SDP_Solver.hxx:28-43; checkpoint / save_solution.cxx:67-150), dx dX dy dY,
- * dual_residues primal_residues primal_residue_p, Q S AXinv AY ...  j = global block
+ * dual_residues c_minus_By (save_c_minus_By.hxx:18-47) primal_residues primal_residue_p, Q S AXinv AY ...  j = global block
  * index (must be owned by this rank), parity 0/1 for block-diagonal members. */
 int sdpb_hip_get_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, char *buf, size_t buflen,
                        size_t *needed);

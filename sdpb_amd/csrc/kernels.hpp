@@ -468,18 +468,19 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
 // Both dot products run over chunks of KC columns whose operands — TR x KC numbers of X
 // (or of T) and PB x KC numbers of L (or of Li) — are fetched once per workgroup into
 // limb-major LDS tiles, so the inner loop is LDS reads + one Acc product per term.
-template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p)
+// One workgroup tile of COLS panel columns x WG/COLS rows (COLS = the power of two that
+// covers the panel's width: a ragged last panel of 8 columns is worked on by 32 rows x 8
+// columns instead of 8 rows x 32 columns with three quarters of the lanes idle).
+template <int NL, int COLS>
+MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const MatDesc &dl, const MatDesc &di, const MatDesc &dx, int k0, int nb,
+                         uint32_t *smem)
 {
-  constexpr int KC = TRSM_KC, SXN = TR * KC, SLN = PB * KC, STN = TR * PB;
-  const int q = blockIdx.y;
-  const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
-  const int k0 = PB * p;
-  if(k0 >= dl.rows || (int)(blockIdx.x * TR) >= dx.rows)
+  constexpr int KC = TRSM_KC, ROWS = WG / COLS, SXN = ROWS * KC, SLN = COLS * KC, STN = ROWS * COLS;
+  uint32_t *sx = smem, *sl = sx + (NL + 2) * SXN, *st = sl + (NL + 2) * SLN;
+  if((int)(blockIdx.x * ROWS) >= dx.rows)
     return;
-  const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
-  const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
-  const int r0 = blockIdx.x * TR, r = r0 + rl;
-  __shared__ uint32_t sx[(NL + 2) * SXN], sl[(NL + 2) * SLN], st[(NL + 2) * STN];
+  const int rl = threadIdx.x % ROWS, j = threadIdx.x / ROWS;
+  const int r0 = blockIdx.x * ROWS, r = r0 + rl;
   const bool ok = r < dx.rows && j < nb;
   Acc<NL> acc = mw::acc_zero<NL>();
   if(ok)
@@ -490,12 +491,12 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
         {
           if(e < SXN)
             {
-              const int kk = e / TR, rr = e % TR;
+              const int kk = e / ROWS, rr = e % ROWS;
               smem_st<NL, SXN>(sx, e, r0 + rr < dx.rows ? mat_ld<NL>(X, dx, r0 + rr, k + kk) : mw::zero<NL>());
             }
           else
             {
-              const int f = e - SXN, kk = f / PB, jj = f % PB;
+              const int f = e - SXN, kk = f / COLS, jj = f % COLS;
               smem_st<NL, SLN>(sl, f, jj < nb ? mat_ld<NL>(L, dl, k0 + jj, k + kk) : mw::zero<NL>());
             }
         }
@@ -504,18 +505,18 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
         {
 #pragma unroll 1
           for(int kk = 0; kk < KC; ++kk)
-            mw::acc_fms(acc, smem_ld<NL, SXN>(sx, kk * TR + rl), smem_ld<NL, SLN>(sl, kk * PB + j));
+            mw::acc_fms(acc, smem_ld<NL, SXN>(sx, kk * ROWS + rl), smem_ld<NL, SLN>(sl, kk * COLS + j));
         }
       __syncthreads();
     }
-  smem_st<NL, STN>(st, j * TR + rl, ok ? mw::acc_result(acc) : mw::zero<NL>());
+  smem_st<NL, STN>(st, j * ROWS + rl, ok ? mw::acc_result(acc) : mw::zero<NL>());
   acc = mw::acc_zero<NL>();
   // X(r, k0+j) = sum_{j2 <= j} T(r, j2) Li(k0+j, k0+j2)
   for(int c = 0; c < nb; c += KC)
     {
       for(int f = threadIdx.x; f < SLN; f += WG)
         {
-          const int kk = f / PB, jj = f % PB;
+          const int kk = f / COLS, jj = f % COLS;
           smem_st<NL, SLN>(sl, f, (jj < nb && c + kk <= jj) ? mat_ld<NL>(Li, di, k0 + jj, k0 + c + kk) : mw::zero<NL>());
         }
       __syncthreads(); // also orders the writes of st before the first read
@@ -524,12 +525,33 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
 #pragma unroll 1
           for(int kk = 0; kk < KC; ++kk)
             if(c + kk <= j)
-              mw::acc_fma(acc, smem_ld<NL, STN>(st, (c + kk) * TR + rl), smem_ld<NL, SLN>(sl, kk * PB + j));
+              mw::acc_fma(acc, smem_ld<NL, STN>(st, (c + kk) * ROWS + rl), smem_ld<NL, SLN>(sl, kk * COLS + j));
         }
       __syncthreads();
     }
   if(ok)
     mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
+}
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p)
+{
+  constexpr int KC = TRSM_KC;
+  const int q = blockIdx.y;
+  const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
+  const int k0 = PB * p;
+  if(k0 >= dl.rows)
+    return;
+  const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
+  // X chunk + L chunk + T tile: (WG/COLS + COLS) KC + WG numbers, largest at COLS = PB and COLS = 8
+  constexpr int MINC = PB < 8 ? PB : 8, NMAX = (WG / MINC + MINC) * KC > (WG / PB + PB) * KC ? (WG / MINC + MINC) * KC : (WG / PB + PB) * KC;
+  __shared__ uint32_t smem[(NL + 2) * (NMAX + WG)];
+  if constexpr(PB >= 32)
+    {
+      if(nb <= 8)
+        return trsm_rlt_tile<NL, 8>(L, Li, X, dl, di, dx, k0, nb, smem);
+      if(nb <= 16)
+        return trsm_rlt_tile<NL, 16>(L, Li, X, dl, di, dx, k0, nb, smem);
+    }
+  trsm_rlt_tile<NL, PB>(L, Li, X, dl, di, dx, k0, nb, smem);
 }
 // X := X L^{-1}, panel p (backward over panels):
 //   T = X(:,panel p) - X(:,cols >= k0+nb) L(rows >= k0+nb, panel p) ;  X(:,panel p) = T Li_pp

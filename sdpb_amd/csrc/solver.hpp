@@ -183,7 +183,7 @@ template <int NL> class Solver : public SolverBase
   // ---- device arrays ---------------------------------------------------------
   DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
   DevArray bases_, E_, Et_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
-  DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_;
+  DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_, cmby_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_, colsum_partial_, syrk_part_;
@@ -1460,6 +1460,15 @@ public:
     if(w == "dx") return {&dx_, (size_t)bd.voff, (size_t)bd.P};
     if(w == "c") return {&c_, (size_t)bd.voff, (size_t)bd.P};
     if(w == "dual_residues") return {&dres_, (size_t)bd.voff, (size_t)bd.P};
+    if(w == "c_minus_By")
+      {
+        // save_c_minus_By.hxx:18-47: c - B y of the current y, all local blocks at once
+        if(cmby_.n < Ptot_)
+          cmby_.alloc(Ptot_, NL);
+        copy(c_, cmby_);
+        launch(k_gemv_n<NL>, dim3(cdiv(max_P_, 4), Jl_), dim3(WG), stream_, btB(BT_), y_.cptr(), cmby_.ptr(), d_blk_.p, N_, -1);
+        return {&cmby_, (size_t)bd.voff, (size_t)bd.P};
+      }
     if(w == "S" || w == "L") return {&S_, (size_t)h_schur_[l].off, (size_t)bd.P * bd.P};
     if(w == "BT") return {&BT_, (size_t)h_bt_[l].off, (size_t)bd.P * N_};
     if(w == "PT") return {&PT_, (size_t)h_bt_[l].off, (size_t)bd.P * N_};

@@ -186,6 +186,11 @@ def solve(argv: Optional[List[str]] = None) -> str:
                 f"primalObjective = {out['primalObjective']};\ndualObjective   = {out['dualObjective']};\n"
                 f"dualityGap      = {out['dualityGap']};\nprimalError     = {out['primalError']};\n"
                 f"dualError       = {out['dualError']};\nSolver runtime  = {runtime};\n")
+    # out/c_minus_By/c_minus_By.json (save_c_minus_By.hxx; read by `spectrum`)
+    os.makedirs(os.path.join(out_dir, "c_minus_By"), exist_ok=True)
+    with open(os.path.join(out_dir, "c_minus_By", "c_minus_By.json"), "w") as f:
+        f.write("{\"c_minus_By\":[" + ",".join(
+            "[" + ",".join(f"\"{v}\"" for v in solver.array("c_minus_By", j)) + "]" for j in range(sdp.J)) + "]}")
     what = set(w for w in o.writeSolution.split(",") if w)
     y = solver.array("y")
     if "y" in what:

@@ -67,6 +67,9 @@ def main():
         xs = sorted(f for f in os.listdir(os.path.join(src, "out")) if f.startswith("x_") and f.endswith(".txt"))
         for f in ["out.txt", "y.txt"] + xs:
             shutil.copy(os.path.join(src, "out", f), os.path.join(dst, f))
+        cmby = os.path.join(src, "out", "c_minus_By", "c_minus_By.json")
+        if os.path.exists(cmby):
+            shutil.copy(cmby, os.path.join(dst, "c_minus_By.json"))
         meta[name] = {"precision": prec, "params": params, "source": source,
                       "reference_dir": "test/data/end-to-end_tests/" + sub}
     with open(os.path.join(HERE, "cases.json"), "w") as f:

@@ -40,6 +40,16 @@ def _check_outputs(name, out_dir, tol_bits=99):
         bad, _ = parity.compare_iteration(g, w, tol_bits)
         assert not bad, (name, w["iteration"], bad)
     golden = os.path.join(parity.GOLDEN, name)
+    if os.path.exists(os.path.join(golden, "c_minus_By.json")):   # save_c_minus_By.hxx
+        with open(os.path.join(out_dir, "c_minus_By", "c_minus_By.json")) as f:
+            mine_c = json.load(f)["c_minus_By"]
+        with open(os.path.join(golden, "c_minus_By.json")) as f:
+            want_c = json.load(f)["c_minus_By"]
+        assert [len(b) for b in mine_c] == [len(b) for b in want_c]
+        scale = max(abs(parity.mpmath.mpf(v)) for b in want_c for v in b)
+        for bm, bw in zip(mine_c, want_c):
+            for u, v in zip(bm, bw):
+                assert abs(parity.mpmath.mpf(u) - parity.mpmath.mpf(v)) <= parity.mpmath.mpf(2) ** -tol_bits * scale
     files = ["y.txt"] + [f"x_{j}.txt" for j in range(sdp.J)]
     for fn in files:
         a, b = _vector(os.path.join(out_dir, fn)), _vector(os.path.join(golden, fn))
