@@ -81,59 +81,59 @@ template <int NL> struct Mw
   while(0)
 #endif
 
-// eight / two MACs in one statement
+// two .. eight MACs in one statement (every asm statement costs a wait state: one statement per column)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MW_MAC_ASM1(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-#define MW_MAC2(lo, hi, a0, b0, a1, b1)                                                          \
+#define MW_MAC2(lo, hi, a0, b0, a1, b1) \
   asm volatile(MW_MAC_ASM1(2, 3) MW_MAC_ASM1(4, 5) : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc")
-#define MW_MAC8(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7)          \
-  asm volatile(MW_MAC_ASM1(2, 3) MW_MAC_ASM1(4, 5) MW_MAC_ASM1(6, 7) MW_MAC_ASM1(8, 9)           \
-                 MW_MAC_ASM1(10, 11) MW_MAC_ASM1(12, 13) MW_MAC_ASM1(14, 15) MW_MAC_ASM1(16, 17) \
-               : "+v"(lo), "+v"(hi)                                                              \
-               : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6),  \
-                 "v"(b6), "v"(a7), "v"(b7)                                                       \
-               : "vcc")
-#else
-#define MW_MAC2(lo, hi, a0, b0, a1, b1)                                        \
-  do                                                                           \
-    {                                                                          \
-      MW_MAC(lo, hi, a0, b0);                                                  \
-      MW_MAC(lo, hi, a1, b1);                                                  \
-    }                                                                          \
-  while(0)
+#define MW_MAC3(lo, hi, a0, b0, a1, b1, a2, b2) \
+  asm volatile(MW_MAC_ASM1(2, 3) MW_MAC_ASM1(4, 5) MW_MAC_ASM1(6, 7) : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2) : "vcc")
+#define MW_MAC5(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4) \
+  asm volatile(MW_MAC_ASM1(2, 3) MW_MAC_ASM1(4, 5) MW_MAC_ASM1(6, 7) MW_MAC_ASM1(8, 9) MW_MAC_ASM1(10, 11) : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4) : "vcc")
+#define MW_MAC6(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5) \
+  asm volatile(MW_MAC_ASM1(2, 3) MW_MAC_ASM1(4, 5) MW_MAC_ASM1(6, 7) MW_MAC_ASM1(8, 9) MW_MAC_ASM1(10, 11) MW_MAC_ASM1(12, 13) : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5) : "vcc")
+#define MW_MAC7(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6) \
+  asm volatile(MW_MAC_ASM1(2, 3) MW_MAC_ASM1(4, 5) MW_MAC_ASM1(6, 7) MW_MAC_ASM1(8, 9) MW_MAC_ASM1(10, 11) MW_MAC_ASM1(12, 13) MW_MAC_ASM1(14, 15) : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6) : "vcc")
 #define MW_MAC8(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7) \
-  do                                                                           \
-    {                                                                          \
-      MW_MAC4(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3);                         \
-      MW_MAC4(lo, hi, a4, b4, a5, b5, a6, b6, a7, b7);                         \
-    }                                                                          \
-  while(0)
+  asm volatile(MW_MAC_ASM1(2, 3) MW_MAC_ASM1(4, 5) MW_MAC_ASM1(6, 7) MW_MAC_ASM1(8, 9) MW_MAC_ASM1(10, 11) MW_MAC_ASM1(12, 13) MW_MAC_ASM1(14, 15) MW_MAC_ASM1(16, 17) : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7) : "vcc")
+#else
+#define MW_MAC2(lo, hi, a0, b0, a1, b1) \
+  do { MW_MAC(lo, hi, a0, b0); MW_MAC(lo, hi, a1, b1); } while(0)
+#define MW_MAC3(lo, hi, a0, b0, a1, b1, a2, b2) \
+  do { MW_MAC(lo, hi, a0, b0); MW_MAC(lo, hi, a1, b1); MW_MAC(lo, hi, a2, b2); } while(0)
+#define MW_MAC5(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4) \
+  do { MW_MAC(lo, hi, a0, b0); MW_MAC(lo, hi, a1, b1); MW_MAC(lo, hi, a2, b2); MW_MAC(lo, hi, a3, b3); MW_MAC(lo, hi, a4, b4); } while(0)
+#define MW_MAC6(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5) \
+  do { MW_MAC(lo, hi, a0, b0); MW_MAC(lo, hi, a1, b1); MW_MAC(lo, hi, a2, b2); MW_MAC(lo, hi, a3, b3); MW_MAC(lo, hi, a4, b4); MW_MAC(lo, hi, a5, b5); } while(0)
+#define MW_MAC7(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6) \
+  do { MW_MAC(lo, hi, a0, b0); MW_MAC(lo, hi, a1, b1); MW_MAC(lo, hi, a2, b2); MW_MAC(lo, hi, a3, b3); MW_MAC(lo, hi, a4, b4); MW_MAC(lo, hi, a5, b5); MW_MAC(lo, hi, a6, b6); } while(0)
+#define MW_MAC8(lo, hi, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7) \
+  do { MW_MAC(lo, hi, a0, b0); MW_MAC(lo, hi, a1, b1); MW_MAC(lo, hi, a2, b2); MW_MAC(lo, hi, a3, b3); MW_MAC(lo, hi, a4, b4); MW_MAC(lo, hi, a5, b5); MW_MAC(lo, hi, a6, b6); MW_MAC(lo, hi, a7, b7); } while(0)
 #endif
 
 // column k of a product: acc += sum_{i=i0..i1} a[i]*b[k-i], compile-time bounds
 template <int I0, int I1, int K, class A, class B> MW_HD void mac_column(uint64_t &lo, uint32_t &hi, const A &a, const B &b)
 {
-  if constexpr(I1 - I0 + 1 >= 8)
+  constexpr int CNT = I1 - I0 + 1;
+  if constexpr(CNT >= 8)
     {
-      MW_MAC8(lo, hi, a[I0], b[K - I0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2], a[I0 + 3], b[K - I0 - 3], a[I0 + 4], b[K - I0 - 4],
-              a[I0 + 5], b[K - I0 - 5], a[I0 + 6], b[K - I0 - 6], a[I0 + 7], b[K - I0 - 7]);
+      MW_MAC8(lo, hi, a[I0 + 0], b[K - I0 - 0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2], a[I0 + 3], b[K - I0 - 3], a[I0 + 4], b[K - I0 - 4], a[I0 + 5], b[K - I0 - 5], a[I0 + 6], b[K - I0 - 6], a[I0 + 7], b[K - I0 - 7]);
       mac_column<I0 + 8, I1, K>(lo, hi, a, b);
     }
-  else if constexpr(I1 - I0 + 1 >= 4)
-    {
-      MW_MAC4(lo, hi, a[I0], b[K - I0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2], a[I0 + 3], b[K - I0 - 3]);
-      mac_column<I0 + 4, I1, K>(lo, hi, a, b);
-    }
-  else if constexpr(I1 - I0 + 1 >= 2)
-    {
-      MW_MAC2(lo, hi, a[I0], b[K - I0], a[I0 + 1], b[K - I0 - 1]);
-      mac_column<I0 + 2, I1, K>(lo, hi, a, b);
-    }
-  else if constexpr(I1 >= I0)
-    {
-      MW_MAC(lo, hi, a[I0], b[K - I0]);
-      mac_column<I0 + 1, I1, K>(lo, hi, a, b);
-    }
+  else if constexpr(CNT == 7)
+    MW_MAC7(lo, hi, a[I0 + 0], b[K - I0 - 0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2], a[I0 + 3], b[K - I0 - 3], a[I0 + 4], b[K - I0 - 4], a[I0 + 5], b[K - I0 - 5], a[I0 + 6], b[K - I0 - 6]);
+  else if constexpr(CNT == 6)
+    MW_MAC6(lo, hi, a[I0 + 0], b[K - I0 - 0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2], a[I0 + 3], b[K - I0 - 3], a[I0 + 4], b[K - I0 - 4], a[I0 + 5], b[K - I0 - 5]);
+  else if constexpr(CNT == 5)
+    MW_MAC5(lo, hi, a[I0 + 0], b[K - I0 - 0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2], a[I0 + 3], b[K - I0 - 3], a[I0 + 4], b[K - I0 - 4]);
+  else if constexpr(CNT == 4)
+    MW_MAC4(lo, hi, a[I0 + 0], b[K - I0 - 0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2], a[I0 + 3], b[K - I0 - 3]);
+  else if constexpr(CNT == 3)
+    MW_MAC3(lo, hi, a[I0 + 0], b[K - I0 - 0], a[I0 + 1], b[K - I0 - 1], a[I0 + 2], b[K - I0 - 2]);
+  else if constexpr(CNT == 2)
+    MW_MAC2(lo, hi, a[I0 + 0], b[K - I0 - 0], a[I0 + 1], b[K - I0 - 1]);
+  else if constexpr(CNT == 1)
+    MW_MAC(lo, hi, a[I0], b[K - I0]);
 }
 
 // ---- pieces of the move-free product used by k_syrk_fx (kernels.hpp) ----------
