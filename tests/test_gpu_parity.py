@@ -160,3 +160,27 @@ def test_rccl_callbacks_alias_device_memory_zero_copy():
         assert torch.equal(send, recv)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_measured_copy_ceiling_is_sane():
+    """sdpb_hip_copy_bandwidth (the measured HBM ceiling bench.py reports next to the 8 TB/s peak)."""
+    from sdpb_amd.solver import copy_bandwidth_gbs
+    gbs = copy_bandwidth_gbs(1 << 28, 3)
+    assert 500.0 < gbs < 8000.0, gbs
+
+
+@pytest.mark.gpu
+def test_c_minus_By_matches_the_oracle_arithmetic():
+    """c - B y of the current iterate (save_c_minus_By.hxx:18-47) against a direct evaluation."""
+    sdp, meta, iters, out = parity.load_case("1d-constraints")
+    s = _solver(sdp, meta["precision"], meta["params"])
+    for _ in range(3):
+        assert not s.iterate()
+    y = [parity.mpmath.mpf(v) for v in s.array("y")]
+    for j, blk in enumerate(sdp.blocks):
+        got = s.array("c_minus_By", j)
+        for p_, (crow, brow) in enumerate(zip(blk.c, blk.B)):
+            want = parity.mpmath.mpf(crow) - sum(parity.mpmath.mpf(b) * yy for b, yy in zip(brow, y))
+            assert abs(parity.mpmath.mpf(got[p_]) - want) <= parity.mpmath.mpf(2) ** -(meta["precision"] - 40) * (1 + abs(want))
+    s.close()
