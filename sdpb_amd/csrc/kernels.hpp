@@ -1284,11 +1284,6 @@ template <int M> MW_HD void syrk_fold(uint32_t (&acc)[2 * M + 2], const uint64_t
       MW_ADDC(acc[k], x, cy);
     }
 }
-#ifndef SDPB_SYRK_UNROLL
-#define SDPB_SYRK_UNROLL 2
-#endif
-#define SDPB_STR_(x) #x
-#define SDPB_UNROLL(n) _Pragma(SDPB_STR_(unroll n))
 // one of the three products over the RB staged rows: planes [P0, P0+M) of both operands
 template <int M, int RB, int PL>
 MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL * RB * 16], int p0, int li, int lj, uint32_t (&acc)[2 * M + 2])
@@ -1301,7 +1296,7 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
       c[k] = 0;
       h[k] = 0;
     }
-  SDPB_UNROLL(SDPB_SYRK_UNROLL)
+#pragma unroll 2
   for(int rr = 0; rr < RB; ++rr)
     {
       uint32_t a[M], b[M];
@@ -1860,25 +1855,43 @@ __global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double 
 
 // (max diag / min diag) per matrix: cholesky_condition_number.hxx:8-37 without the
 // final square (done on the host for the winner only).
-template <int NL> __global__ void __launch_bounds__(WG) k_diag_ratio(Batch L, mw::Ptr out, size_t out_off)
+// one wavefront per matrix: lanes scan the diagonal with stride 64, then an LDS tree
+constexpr int DR_T = 64;
+template <int NL> __global__ void __launch_bounds__(DR_T) k_diag_ratio(Batch L, mw::Ptr out, size_t out_off)
 {
-  const int q = blockIdx.x * WG + threadIdx.x;
-  if(q >= L.count)
-    return;
+  const int q = blockIdx.x, t = threadIdx.x;
   const MatDesc d = L.d[q];
-  Mw<NL> r = mw::zero<NL>();
-  if(d.rows > 0)
+  __shared__ Mw<NL> smx[DR_T], smn[DR_T];
+  __shared__ int shas[DR_T];
+  bool has = t < d.rows;
+  Mw<NL> mx = mw::zero<NL>(), mn = mw::zero<NL>();
+  if(has)
     {
-      Mw<NL> mx = mat_ld<NL>(L, d, 0, 0), mn = mx;
-      for(int i = 1; i < d.rows; ++i)
+      mx = mat_ld<NL>(L, d, t, t);
+      mn = mx;
+      for(int i = t + DR_T; i < d.rows; i += DR_T)
         {
           const Mw<NL> v = mat_ld<NL>(L, d, i, i);
           mx = mw::max(mx, v);
           mn = mw::min(mn, v);
         }
-      r = mw::div(mx, mn);
     }
-  mw::store<NL>(out, out_off + q, r);
+  smx[t] = mx;
+  smn[t] = mn;
+  shas[t] = has ? 1 : 0;
+  __syncthreads();
+  for(int s = DR_T / 2; s > 0; s >>= 1)
+    {
+      if(t < s && shas[t + s])
+        {
+          smx[t] = shas[t] ? mw::max(smx[t], smx[t + s]) : smx[t + s];
+          smn[t] = shas[t] ? mw::min(smn[t], smn[t + s]) : smn[t + s];
+          shas[t] = 1;
+        }
+      __syncthreads();
+    }
+  if(t == 0)
+    mw::store<NL>(out, out_off + q, d.rows > 0 ? mw::div(smx[0], smn[0]) : mw::zero<NL>());
 }
 
 // ---- multi-GPU exchange images ----------------------------------------------

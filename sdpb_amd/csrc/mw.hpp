@@ -136,40 +136,19 @@ template <int I0, int I1, int K, class A, class B> MW_HD void mac_column(uint64_
     MW_MAC(lo, hi, a[I0], b[K - I0]);
 }
 
-// ---- pieces of the move-free product used by k_syrk_fx (kernels.hpp) ----------
-// Carry: a carry flag that lives across statements (a lane mask in an SGPR pair).
+// ---- carry chains that span statements -----------------------------------------
+// Carry: a carry flag that lives across statements (on the device a lane mask in an SGPR
+// pair, so that chains can be interleaved with the VCC-based MAC statements above).
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned long long Carry;
-#ifndef MW_ASMQ
-#define MW_ASMQ
-#endif
-// c = a*b
-#define MW_MUL64(c, a, b) asm MW_ASMQ("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b) : "vcc")
-// c += a*b for c < 2^33: cannot carry out of 64 bits
-#define MW_MAC_NC(c, a, b) asm MW_ASMQ("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc")
-// c += a*b, h = the carry (h is defined here, not accumulated)
-#define MW_MAC_H0(c, h, a, b)                                                                    \
-  asm MW_ASMQ("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc"               \
-      : "+v"(c), "=v"(h)                                                                         \
-      : "v"(a), "v"(b)                                                                           \
-      : "vcc")
-#define MW_CY_SET(cy, bit) asm MW_ASMQ("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(cy) : "v"(bit))
+// cy = (bit != 0)
+#define MW_CY_SET(cy, bit) asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(cy) : "v"(bit))
 // d += x, cy = carry out
-#define MW_ADD_CO(d, x, cy) asm MW_ASMQ("v_add_co_u32_e64 %0, %1, %0, %2" : "+v"(d), "=s"(cy) : "v"(x))
+#define MW_ADD_CO(d, x, cy) asm("v_add_co_u32_e64 %0, %1, %0, %2" : "+v"(d), "=s"(cy) : "v"(x))
 // d += x + cy, cy = carry out
-#define MW_ADDC(d, x, cy) asm MW_ASMQ("v_addc_co_u32_e64 %0, %1, %0, %2, %1" : "+v"(d), "+s"(cy) : "v"(x))
+#define MW_ADDC(d, x, cy) asm("v_addc_co_u32_e64 %0, %1, %0, %2, %1" : "+v"(d), "+s"(cy) : "v"(x))
 #else
 typedef uint32_t Carry;
-#define MW_MUL64(c, a, b) c = (uint64_t)(a) * (uint64_t)(b)
-#define MW_MAC_NC(c, a, b) c += (uint64_t)(a) * (uint64_t)(b)
-#define MW_MAC_H0(c, h, a, b)                                                  \
-  do                                                                           \
-    {                                                                          \
-      const uint64_t p__ = (uint64_t)(a) * (uint64_t)(b);                      \
-      c += p__;                                                                \
-      h = (c < p__) ? 1u : 0u;                                                 \
-    }                                                                          \
-  while(0)
 #define MW_CY_SET(cy, bit) cy = ((bit) != 0) ? 1u : 0u
 #define MW_ADD_CO(d, x, cy)                                                    \
   do                                                                           \

@@ -1243,11 +1243,11 @@ private:
     const int J1 = std::max(Jl_, 1);
     if(Jl_)
       {
-        launch(k_diag_ratio<NL>, dim3(cdiv(Jl_, WG)), dim3(WG), stream_, schurB(), ratio_.ptr(), (size_t)0);
-        launch(k_diag_ratio<NL>, dim3(cdiv(2 * Jl_, WG)), dim3(WG), stream_, psd(Xc_), ratio_.ptr(), (size_t)J1);
-        launch(k_diag_ratio<NL>, dim3(cdiv(2 * Jl_, WG)), dim3(WG), stream_, psd(Yc_), ratio_.ptr(), (size_t)3 * J1);
+        launch(k_diag_ratio<NL>, dim3(Jl_), dim3(DR_T), stream_, schurB(), ratio_.ptr(), (size_t)0);
+        launch(k_diag_ratio<NL>, dim3(2 * Jl_), dim3(DR_T), stream_, psd(Xc_), ratio_.ptr(), (size_t)J1);
+        launch(k_diag_ratio<NL>, dim3(2 * Jl_), dim3(DR_T), stream_, psd(Yc_), ratio_.ptr(), (size_t)3 * J1);
       }
-    launch(k_diag_ratio<NL>, dim3(1), dim3(WG), stream_, QB(), ratio_.ptr(), (size_t)5 * J1);
+    launch(k_diag_ratio<NL>, dim3(1), dim3(DR_T), stream_, QB(), ratio_.ptr(), (size_t)5 * J1);
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<M> r = download<NL>(ratio_, 0, (size_t)5 * J1 + 1);
     Q_cond_number_ = mw::mul(r[5 * J1], r[5 * J1]);
