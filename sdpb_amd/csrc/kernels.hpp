@@ -1296,17 +1296,27 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
       c[k] = 0;
       h[k] = 0;
     }
-#pragma unroll 2
-  for(int rr = 0; rr < RB; ++rr)
-    {
-      uint32_t a[M], b[M];
+  auto row = [&](int rr) __attribute__((always_inline)) {
+    uint32_t a[M], b[M];
 #pragma unroll
-      for(int l = 0; l < M; ++l)
-        {
-          a[l] = sa[((p0 + l) * RB + rr) * 16 + li];
-          b[l] = sb[((p0 + l) * RB + rr) * 16 + lj];
-        }
-      SyrkColumns<M, 0>::run(a, b, c, h);
+    for(int l = 0; l < M; ++l)
+      {
+        a[l] = sa[((p0 + l) * RB + rr) * 16 + li];
+        b[l] = sb[((p0 + l) * RB + rr) * 16 + lj];
+      }
+    SyrkColumns<M, 0>::run(a, b, c, h);
+  };
+  if constexpr(M <= 12)
+    {
+#pragma unroll 2
+      for(int rr = 0; rr < RB; ++rr)
+        row(rr);
+    }
+  else
+    {
+#pragma unroll 1
+      for(int rr = 0; rr < RB; ++rr)
+        row(rr);
     }
   syrk_fold<M>(acc, c, h);
 }
@@ -1324,7 +1334,7 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
 // one split the output goes straight to acc.  The host picks nsplit so that
 // tiles * nsplit fills a whole number of rounds of resident workgroups (syrk_row_splits).
 #ifndef SDPB_SYRK_WAVES
-#define SDPB_SYRK_WAVES (FX <= 16 ? 4 : 2) // measured: 4 waves without splits beat 3 waves with splits at N = 1000
+#define SDPB_SYRK_WAVES (FX <= 16 ? 3 : 2) // 3 waves x 168 VGPRs hold the staging registers of the pipeline without spills
 #endif
 template <int FX> constexpr int syrk_waves_per_simd() { return SDPB_SYRK_WAVES; }
 // nsplit in [1, 16]: fewest splits within 2% of the best occupancy of the last round
@@ -1376,25 +1386,91 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 #pragma unroll
   for(int k = 0; k < A; ++k)
     ll[k] = hh[k] = ss[k] = 0;
-  for(unsigned r0 = row_begin; r0 < row_end; r0 += RB)
+  // The three products read disjoint plane groups (lo, hi, s), so the staging of the next
+  // chunk is software-pipelined through the passes with a single LDS image: while one group
+  // is being multiplied, the group that became free one pass ago is fetched into GL
+  // registers per lane, and it is written to LDS when the pass ends:
+  //   LL(c) | store s(c)    | barrier | fetch lo(c+1)
+  //   HH(c) | store lo(c+1) | barrier | fetch hi(c+1)
+  //   SS(c) | store hi(c+1) | barrier | fetch s(c+1)
+  // (a barrier both publishes the stores and certifies that every wavefront has left the
+  // pass whose group is fetched next).  Without this the global-load latency of a chunk
+  // was exposed: 13 % of the kernel.
+  constexpr int GE = M * RB * 16, GL = (GE + WG - 1) / WG; // elements of one plane group, per lane
+  uint32_t va[GL], vb[GL];
+  auto fetch = [&](int g, unsigned r0) __attribute__((always_inline)) {
+#pragma unroll
+    for(int t = 0; t < GL; ++t)
+      {
+        const int e = threadIdx.x + t * WG;
+        const int col = e & 15, rr = (e >> 4) % RB, pl = g * M + (e >> 4) / RB;
+        const unsigned r = r0 + rr;
+        const int ca = ti * 16 + col, cb = tj * 16 + col;
+        const bool ok = e < GE && r < row_end;
+        // lanes outside the image read a valid element and drop it: no divergent branches
+        const uint32_t *row = fx + (size_t)(e < GE ? pl : 0) * fx_stride + (size_t)(ok ? r : row_begin) * (size_t)N;
+        const uint32_t xa = row[ca < N ? ca : 0], xb = row[cb < N ? cb : 0];
+        va[t] = (ok && ca < N) ? xa : 0u; // rows past the end and columns past N: zero limbs,
+        vb[t] = (ok && cb < N) ? xb : 0u; // they add nothing to any product
+      }
+  };
+  auto store = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for(int t = 0; t < GL; ++t)
+      {
+        const int e = threadIdx.x + t * WG;
+        if(e < GE)
+          {
+            sa[g * GE + e] = va[t];
+            sb[g * GE + e] = vb[t];
+          }
+      }
+  };
+  if constexpr(FX <= 24)
     {
-      // stage: PL planes x RB rows x 16 columns for each operand (rows past the end and
-      // columns past N read as zero limbs: they add nothing to any product)
-      for(int e = threadIdx.x; e < PL * RB * 16; e += WG)
+      fetch(0, row_begin);
+      store(0);
+      fetch(1, row_begin);
+      store(1);
+      __syncthreads();
+      fetch(2, row_begin);
+      for(unsigned r0 = row_begin; r0 < row_end; r0 += RB)
         {
-          const int col = e & 15, rr = (e >> 4) % RB, pl = (e >> 4) / RB;
-          const unsigned r = r0 + rr;
-          const int ca = ti * 16 + col, cb = tj * 16 + col;
-          const bool okr = r < row_end;
-          const uint32_t *row = fx + (size_t)pl * fx_stride + (size_t)r * (size_t)N;
-          sa[e] = (okr && ca < N) ? row[ca] : 0u;
-          sb[e] = (okr && cb < N) ? row[cb] : 0u;
+          syrk_rows<M, RB, PL>(sa, sb, 0, li, lj, ll);
+          store(2);
+          __syncthreads();
+          fetch(0, r0 + RB);
+          syrk_rows<M, RB, PL>(sa, sb, M, li, lj, hh);
+          store(0);
+          __syncthreads();
+          fetch(1, r0 + RB);
+          syrk_rows<M, RB, PL>(sa, sb, 2 * M, li, lj, ss);
+          store(1);
+          __syncthreads();
+          fetch(2, r0 + RB);
         }
-      __syncthreads();
-      syrk_rows<M, RB, PL>(sa, sb, 0, li, lj, ll);
-      syrk_rows<M, RB, PL>(sa, sb, M, li, lj, hh);
-      syrk_rows<M, RB, PL>(sa, sb, 2 * M, li, lj, ss);
-      __syncthreads();
+    }
+  else
+    {
+      // 1024-bit operands: accumulators and column sums leave no registers for the pipeline
+      for(unsigned r0 = row_begin; r0 < row_end; r0 += RB)
+        {
+          for(int e = threadIdx.x; e < PL * RB * 16; e += WG)
+            {
+              const int col = e & 15, rr = (e >> 4) % RB, pl = (e >> 4) / RB;
+              const unsigned r = r0 + rr;
+              const int ca = ti * 16 + col, cb = tj * 16 + col;
+              const bool okr = r < row_end;
+              const uint32_t *row = fx + (size_t)pl * fx_stride + (size_t)r * (size_t)N;
+              sa[e] = (okr && ca < N) ? row[ca] : 0u;
+              sb[e] = (okr && cb < N) ? row[cb] : 0u;
+            }
+          __syncthreads();
+          syrk_rows<M, RB, PL>(sa, sb, 0, li, lj, ll);
+          syrk_rows<M, RB, PL>(sa, sb, M, li, lj, hh);
+          syrk_rows<M, RB, PL>(sa, sb, 2 * M, li, lj, ss);
+          __syncthreads();
+        }
     }
   if(i < N && j <= i)
     {

@@ -155,7 +155,7 @@ template <int NL> class Solver : public SolverBase
   using M = Mw<NL>;
   static constexpr int FX = NL - 2; // 32*FX = GMP's rounded precision 64*(l-1) (compute_Q.cxx:107)
   static constexpr int ACCW = 2 * FX + 2;
-  static constexpr int SYRK_RB = 8;
+  static constexpr int SYRK_RB = FX <= 24 ? 16 : 8; // rows per LDS chunk of k_syrk_fx (LDS: 3 FX/2 planes x RB x 16 x 2 operands)
 
   // ---- problem shape -------------------------------------------------------
   int precision_, J_, N_, rank_, world_;
