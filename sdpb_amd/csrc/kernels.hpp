@@ -1308,7 +1308,7 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
   };
   if constexpr(M <= 12)
     {
-#pragma unroll 2
+#pragma unroll 4
       for(int rr = 0; rr < RB; ++rr)
         row(rr);
     }
