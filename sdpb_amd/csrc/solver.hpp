@@ -183,13 +183,13 @@ template <int NL> class Solver : public SolverBase
   // ---- device arrays ---------------------------------------------------------
   DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
   DevArray bases_, E_, Et_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
-  DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_, cmby_;
+  DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_, eigD2_, eigE2_, cmby_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
-  DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, ratio_, scal_;
+  DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, lam2_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_, colsum_partial_, syrk_part_;
   int num_cus_ = 256;
   unsigned colsum_slices_ = 1;
-  DevBuf<double> eigF_;
+  DevBuf<double> eigF_, eigF2_;
   DevBuf<unsigned long long> acc64_;
   DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
   size_t fx_stride_ = 0, acc_stride_ = 0;
@@ -380,18 +380,20 @@ private:
     PT_.alloc(off_bt, NL);
     for(DevArray *a : {&c_, &x_, &dx_, &dres_, &invdS_})
       a->alloc(Ptot_, NL);
-    for(DevArray *a : {&invdX_, &invdY_, &eigD_, &eigE_})
+    for(DevArray *a : {&invdX_, &invdY_, &eigD_, &eigE_, &eigD2_, &eigE2_})
       a->alloc(off_vecn, NL);
     for(DevArray *a : {&b_, &y_, &dy_, &rp_, &norms_, &invnorms_, &invdQ_})
       a->alloc(N_, NL);
     Q_.alloc((size_t)N_ * N_, NL);
     eigF_.alloc(2 * (off_vecn + 1));
+    eigF2_.alloc(2 * (off_vecn + 1));
     LiQ_.alloc((size_t)N_ * N_, NL);
     qtmpv_.alloc(N_, NL);
     part_.alloc((size_t)std::max(Jl_, 1) * N_, NL);
     red_.alloc(1024, NL);
     red2_.alloc(4, NL);
     lam_.alloc(std::max(2 * Jl_, 1), NL);
+    lam2_.alloc(std::max(2 * Jl_, 1), NL);
     ratio_.alloc((size_t)5 * std::max(Jl_, 1) + 1, NL);
     scal_.alloc(S_COUNT, NL);
     fx_stride_ = off_bt ? off_bt : 1;
@@ -1210,19 +1212,46 @@ private:
   }
 
   // step_length.cxx:27-46
-  M step_length(const DevArray &Lc, const DevArray &Li, const DevArray &dM, const char *name)
+  // lambda_min(L^{-1} dM L^{-T}) of every local PSD block into lam (step_length.cxx:27-46 up to the
+  // reduction), enqueued on stream_
+  void enqueue_min_eigenvalues(const DevArray &Lc, const DevArray &Li, const DevArray &dM, DevArray &W, DevArray &D, DevArray &E,
+                               DevBuf<double> &F, DevArray &lam)
   {
-    Timer t(this, name);
-    copy(dM, W_);
+    copy(dM, W);
     // W = L^{-1} dM L^{-T} (lower_triangular_inverse_congruence.cxx:4-16): W1 = dM L^{-T}, then
     // W = (W1^T L^{-T}) since the result is symmetric — both solves run on rows
-    trsm_rlt(psd(Lc), psd(Li), psd(W_), max_n_, max_n_);
-    launch(k_transpose<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(W_));
-    trsm_rlt(psd(Lc), psd(Li), psd(W_), max_n_, max_n_);
-    launch(k_tridiag<NL>, dim3(2 * Jl_), dim3(TRI_T), stream_, psd(W_), vecn(eigD_), vecn(eigE_));
-    launch(k_tridiag_min<NL>, dim3(cdiv(2 * Jl_, EIG_T)), dim3(EIG_T), stream_, vecn(eigD_), vecn(eigE_), eigF_.p, eigF_.p + psd_rows_local_ + 1,
-           lam_.ptr());
-    mw::CPtr lp = lam_.cptr();
+    trsm_rlt(psd(Lc), psd(Li), psd(W), max_n_, max_n_);
+    launch(k_transpose<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(W));
+    trsm_rlt(psd(Lc), psd(Li), psd(W), max_n_, max_n_);
+    launch(k_tridiag<NL>, dim3(2 * Jl_), dim3(TRI_T), stream_, psd(W), vecn(D), vecn(E));
+    launch(k_tridiag_min<NL>, dim3(cdiv(2 * Jl_, EIG_T)), dim3(EIG_T), stream_, vecn(D), vecn(E), F.p, F.p + psd_rows_local_ + 1, lam.ptr());
+  }
+  // The primal and the dual step length are two independent latency-bound chains (Householder
+  // steps, one-lane Newton): they run concurrently, X on the main stream and Y on the stream
+  // Cholesky(Q) used earlier in the iteration (Z is free by now and serves as Y's work matrix).
+  void step_lengths()
+  {
+    {
+      Timer t(this, "stepLength(XCholesky)"); // both chains; the reductions are timed under the Y name
+      if(Jl_)
+        {
+          HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
+          HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
+          enqueue_min_eigenvalues(Xc_, LiX_, dX_, W_, eigD_, eigE_, eigF_, lam_);
+          std::swap(stream_, stream_q_);
+          enqueue_min_eigenvalues(Yc_, LiY_, dY_, Z_, eigD2_, eigE2_, eigF2_, lam2_);
+          HIP_CHECK(hipEventRecord(ev_q_done_, stream_));
+          std::swap(stream_, stream_q_);
+          HIP_CHECK(hipStreamWaitEvent(stream_, ev_q_done_, 0));
+        }
+    }
+    Timer t(this, "stepLength(YCholesky)");
+    primal_step_length_ = step_length_from(lam_);
+    dual_step_length_ = step_length_from(lam2_);
+  }
+  M step_length_from(const DevArray &lam)
+  {
+    mw::CPtr lp = lam.cptr();
     M lambda = reduce<RED_MIN>((size_t)2 * Jl_, [=] __device__(size_t i) { return mw::load<NL>(lp, i); });
     if(Jl_ == 0)
       {
@@ -1358,8 +1387,7 @@ private:
       compute_search_direction(beta_corrector_, true);
     }
     update_cond_numbers();
-    primal_step_length_ = step_length(Xc_, LiX_, dX_, "stepLength(XCholesky)");
-    dual_step_length_ = step_length(Yc_, LiY_, dY_, "stepLength(YCholesky)");
+    step_lengths();
     if(feasible)
       {
         primal_step_length_ = mw::min(primal_step_length_, dual_step_length_);
