@@ -192,6 +192,7 @@ template <int NL> class Solver : public SolverBase
   DevBuf<double> eigF_, eigF2_;
   DevBuf<unsigned long long> acc64_;
   DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
+  DevBuf<int> flags2_; // chol fail of Y (factored on the side stream concurrently with X)
   size_t fx_stride_ = 0, acc_stride_ = 0;
 
   // ---- parameters (Solver_Parameters.hxx:13-30) --------------------------------
@@ -417,6 +418,7 @@ private:
         xrecv_.alloc((size_t)(NL + 2) * std::max(N_, 16) * world_);
       }
     flags_.alloc((size_t)2 * std::max(Jl_, 1) + 4);
+    flags2_.alloc((size_t)2 * std::max(Jl_, 1));
   }
 
   void set_default_params()
@@ -737,10 +739,11 @@ private:
   {
     launch(k_symmetrize<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(A), (int)negate);
   }
-  void check_chol_flags(int count, const char *what, bool schur)
+  void check_chol_flags(int count, const char *what, bool schur) { check_chol_flags(count, what, schur, flags_); }
+  void check_chol_flags(int count, const char *what, bool schur, DevBuf<int> &flags)
   {
     HIP_CHECK(hipStreamSynchronize(stream_));
-    std::vector<int> f = flags_.download();
+    std::vector<int> f = flags.download();
     for(int q = 0; q < count; ++q)
       if(f[q])
         {
@@ -824,14 +827,6 @@ private:
       launch(k_trsm_rln_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, p);
   }
 
-  // cholesky_decomposition.cxx:5-28
-  void cholesky_psd(const DevArray &A, DevArray &L, DevArray &invd, DevArray &Li, const char *name)
-  {
-    copy(A, L);
-    clear_flags();
-    blocked_cholesky(psd(L), vecn(invd), psd(Li), max_n_, flags_.p);
-    check_chol_flags(2 * Jl_, name, false);
-  }
   // C = (+/-) A B (+ C) on the PSD-shaped batch; sub != nullptr fuses "- sub"; trans_out
   // stores the transpose
   void gemm_psd(const DevArray &A, const DevArray &B, DevArray &C, bool alpha_neg, bool beta_one, const DevArray *sub = nullptr,
@@ -870,16 +865,47 @@ private:
   void compute_bilinear_pairings()
   {
     Timer t(this, "bilinear_pairings");
+    compute_A_X_inv();
+    // A_Y and the factor of Y were queued on the side stream by factor_X_and_Y()
+    HIP_CHECK(hipStreamWaitEvent(stream_, ev_q_done_, 0));
+    check_chol_flags(2 * Jl_, "Y", false, flags2_);
+  }
+  // A_X_inv = (Xc^{-1} E)^T (Xc^{-1} E)      compute_A_X_inv.cxx:18-29
+  // computed on the transpose: Tt = E^T Xc^{-T} (row solves), A_X_inv = Tt Tt^T
+  void compute_A_X_inv()
+  {
     const unsigned tiles_q = cdiv(max_q_, 16) * cdiv(max_q_, 16);
-    // A_X_inv = (Xc^{-1} E)^T (Xc^{-1} E)      compute_A_X_inv.cxx:18-29
-    // computed on the transpose: Tt = E^T Xc^{-T} (row solves), A_X_inv = Tt Tt^T
     copy(Et_, T_);
     trsm_rlt(psd(Xc_), psd(LiX_), etB(T_), max_q_, max_n_);
     launch(k_gemm<NL, false, true>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, etB(T_), etB(T_), pairB(AX_), 0, 0, 1, pairB(AX_), 0, 0);
-    // A_Y = E^T (Y E)                           compute_A_Y.cxx:30-45
+  }
+  // A_Y = E^T (Y E)                           compute_A_Y.cxx:30-45
+  void compute_A_Y()
+  {
+    const unsigned tiles_q = cdiv(max_q_, 16) * cdiv(max_q_, 16);
     launch(k_gemm<NL, false, false>, dim3(cdiv(max_n_, 16) * cdiv(max_q_, 16), 2 * Jl_), dim3(WG), stream_, psd(Y_), eB(E_), eB(YQ_), 0, 0,
            0, eB(YQ_), 0, 0);
     launch(k_gemm<NL, true, false>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, eB(E_), eB(YQ_), pairB(AY_), 0, 0, 1, pairB(AY_), 0, 0);
+  }
+  // cholesky_decomposition.cxx:5-28 for X and Y (run.cxx:386-387).  The factor of a batch of
+  // small matrices is a latency-bound chain of pivots, so Y's factor and A_Y (which needs
+  // only Y) go to the side stream while X's factor and A_X_inv run on the main stream.
+  void factor_X_and_Y()
+  {
+    Timer t(this, "choleskyDecomposition");
+    HIP_CHECK(hipMemsetAsync(flags_.p, 0, flags_.n * sizeof(int), stream_));
+    HIP_CHECK(hipMemsetAsync(flags2_.p, 0, flags2_.n * sizeof(int), stream_));
+    HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
+    HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
+    std::swap(stream_, stream_q_);
+    copy(Y_, Yc_);
+    blocked_cholesky(psd(Yc_), vecn(invdY_), psd(LiY_), max_n_, flags2_.p);
+    compute_A_Y();
+    HIP_CHECK(hipEventRecord(ev_q_done_, stream_));
+    std::swap(stream_, stream_q_);
+    copy(X_, Xc_);
+    blocked_cholesky(psd(Xc_), vecn(invdX_), psd(LiX_), max_n_, flags_.p);
+    check_chol_flags(2 * Jl_, "X", false, flags_);
   }
 
   M max_abs(const DevArray &a, size_t count)
@@ -1420,11 +1446,7 @@ public:
   {
     iteration_ += 1;
     compute_objectives();
-    {
-      Timer t(this, "choleskyDecomposition");
-      cholesky_psd(X_, Xc_, invdX_, LiX_, "X");
-      cholesky_psd(Y_, Yc_, invdY_, LiY_, "Y");
-    }
+    factor_X_and_Y();
     compute_bilinear_pairings();
     compute_dual_residues_and_error();
     compute_primal_residues_P();
