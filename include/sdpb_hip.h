@@ -102,6 +102,11 @@ int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, 
 int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j);
 /* 32-bit limbs of the device mantissa chosen for precision_bits. */
 int sdpb_hip_limbs(sdpb_hip_ctx *ctx);
+/* Fraction bits FB of the fixed-point image of the normalised P' that the exact integer
+ * Q' = P'^T P' is formed from (the reference keeps El::gmp::Precision() bits,
+ * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here 32 (limbs-2) - 7, or - 3 for the
+ * limb counts that use one Karatsuba level): inputs of sdpb_hip_op_int_syrk obey |v| < 2^FB. */
+int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx);
 
 /* Cross-GPU exchange (world_size > 1), replacing the El::mpi collectives listed in
  * SURVEY.md §2a.  The library hands DEVICE pointers it owns to these callbacks:

@@ -39,6 +39,8 @@ def lib():
         L.orc_set_param.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
         L.orc_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 4
         L.orc_set_block.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_char_p] * 4
+        L.orc_set_block_f64.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
+                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.orc_set_objective.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
         L.orc_init_state.argtypes = [ctypes.c_void_p]
         L.orc_iterate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
@@ -55,6 +57,8 @@ def lib():
         L.orc_parse_exact.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.orc_scalar_op.restype = ctypes.c_char_p
         L.orc_scalar_op.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 3
+        L.orc_set_threads.restype = ctypes.c_int
+        L.orc_set_threads.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 
@@ -66,9 +70,14 @@ class OracleError(RuntimeError):
 class Oracle:
     """GMP-mpf restatement of the reference iteration, driven like the product solver."""
 
-    def __init__(self, sdp, precision: int, params: dict | None = None, param_prec: int = 64):
+    def __init__(self, sdp, precision: int, params: dict | None = None, param_prec: int = 64,
+                 threads: int = 0, block_source=None):
+        """threads: host threads for the block/column loops (0 = $ORACLE_THREADS or all cores;
+        results are bit-identical for any count).  block_source(j) -> (bases_even, bases_odd,
+        B float64 [P,N], c float64 [P]) feeds blocks lazily (sdpb_amd.synthetic.make_lazy)."""
         from sdpb_amd.sdp_io import block_text  # pure-python I/O helper, no compute
         self.L = lib()
+        self.threads = self.L.orc_set_threads(int(threads))
         J = sdp.J
         dims = (ctypes.c_int * J)(*sdp.dims)
         npts = (ctypes.c_int * J)(*sdp.num_points)
@@ -84,8 +93,19 @@ class Oracle:
         self.L.orc_set_flags(self.h, flags["maxIterations"], flags["findPrimalFeasible"],
                              flags["findDualFeasible"], flags["detectPrimalFeasibleJump"],
                              flags["detectDualFeasibleJump"])
-        for j, blk in enumerate(sdp.blocks):
-            self._chk(self.L.orc_set_block(self.h, j, *block_text(blk)))
+        if block_source is not None:
+            import numpy as np
+            dp = ctypes.POINTER(ctypes.c_double)
+            for j in range(J):
+                be, bo, Bv, cv = block_source(j)
+                Bv = np.ascontiguousarray(Bv, dtype=np.float64)
+                cv = np.ascontiguousarray(cv, dtype=np.float64)
+                flat = lambda rows: " ".join(" ".join(r) for r in rows).encode()
+                self._chk(self.L.orc_set_block_f64(self.h, j, flat(be), flat(bo), Bv.ctypes.data_as(dp),
+                                                   cv.ctypes.data_as(dp)))
+        else:
+            for j, blk in enumerate(sdp.blocks):
+                self._chk(self.L.orc_set_block(self.h, j, *block_text(blk)))
         self._chk(self.L.orc_set_objective(self.h, " ".join(sdp.b).encode(),
                                            sdp.constant.encode()))
         self._chk(self.L.orc_init_state(self.h))

@@ -32,8 +32,42 @@
 #include <string>
 #include <vector>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 namespace
 {
+// Independent units (SDP blocks, matrix columns, output entries) are spread over the host
+// cores with OpenMP.  Only loops whose iterations write disjoint outputs are parallel and
+// every sum keeps its sequential order, so the results are bit-identical for any thread
+// count (tests/test_oracle_golden.py runs the goldens at 1 and at all threads).
+// ORACLE_THREADS / orc_set_threads() choose the count (default: all cores).
+template <class Fn> void parallel_for(int count, Fn fn)
+{
+  std::string err;
+  int err_at = -1;
+#pragma omp parallel for schedule(dynamic, 1)
+  for(int i = 0; i < count; ++i)
+    {
+      try
+        {
+          fn(i);
+        }
+      catch(std::exception &e)
+        {
+#pragma omp critical(oracle_error)
+          if(err_at < 0 || i < err_at)
+            {
+              err_at = i;
+              err = e.what();
+            }
+        }
+    }
+  if(err_at >= 0)
+    throw std::runtime_error(err);
+}
+
 // ---------------------------------------------------------------------------
 // Minimal RAII mpf wrapper (El::BigFloat == mpf at the default precision,
 // src/sdpb_util/Environment.cxx:29-36 -> mpf_set_default_prec).
@@ -245,7 +279,6 @@ void cholesky_lower(Mat &A)
 void cholesky_upper(Mat &A)
 {
   const int n = A.h;
-  F tmp;
   for(int j = 0; j < n; ++j)
     {
       if(mpf_sgn(A(j, j).v) <= 0)
@@ -253,9 +286,13 @@ void cholesky_upper(Mat &A)
       A(j, j) = fsqrt(A(j, j));
       for(int c = j + 1; c < n; ++c)
         A(j, c) /= A(j, j);
+#pragma omp parallel for schedule(static, 8) if(n - j > 64)
       for(int c = j + 1; c < n; ++c)
-        for(int r = j + 1; r <= c; ++r)
-          fms_(A(r, c), A(j, r), A(j, c), tmp);
+        {
+          F t;
+          for(int r = j + 1; r <= c; ++r)
+            fms_(A(r, c), A(j, r), A(j, c), t);
+        }
     }
   for(int j = 0; j < n; ++j)
     for(int i = j + 1; i < n; ++i)
@@ -597,8 +634,8 @@ void compute_objectives(Oracle &o)
 // cholesky_decomposition.cxx:5-28
 void cholesky_decomposition(Oracle &o, bool isX)
 {
-  for(int j = 0; j < o.J; ++j)
-    for(int b = 0; b < 2; ++b)
+  parallel_for(2 * o.J, [&](int jb) {
+    const int j = jb / 2, b = jb % 2;
       {
         Block &bl = o.blk[j];
         Mat &L = isX ? bl.Xc[b] : bl.Yc[b];
@@ -617,14 +654,16 @@ void cholesky_decomposition(Oracle &o, bool isX)
             throw std::runtime_error(ss.str());
           }
       }
+  });
 }
 
 // compute_A_X_inv.cxx:6-58 and compute_A_Y.cxx:16-66
 void compute_bilinear_pairings(Oracle &o)
 {
-  F tmp;
-  for(auto &bl : o.blk)
-    for(int b = 0; b < 2; ++b)
+  parallel_for(2 * o.J, [&](int jb) {
+    Block &bl = o.blk[jb / 2];
+    const int b = jb % 2;
+    F tmp;
       {
         const int q = bl.m * bl.K, n = bl.n[b];
         // A_X_inv = (L^{-1} E)^T (L^{-1} E), Syrk LOWER then MakeSymmetric
@@ -655,13 +694,16 @@ void compute_bilinear_pairings(Oracle &o)
               AY(j, i) = acc;
             }
       }
+  });
 }
 
 // compute_dual_residues_and_error.cxx:7-66
 void compute_dual_residues_and_error(Oracle &o)
 {
-  F local_max, tmp;
-  for(auto &bl : o.blk)
+  std::vector<F> block_max(o.J);
+  parallel_for(o.J, [&](int jj) {
+    Block &bl = o.blk[jj];
+    F tmp, &local_max = block_max[jj];
     {
       for(auto &v : bl.dual_residues)
         mpf_set_ui(v.v, 0);
@@ -684,15 +726,21 @@ void compute_dual_residues_and_error(Oracle &o)
           local_max = fmax_(local_max, fabs_(bl.dual_residues[p]));
         }
     }
+  });
+  F local_max; // a maximum is exact: any order gives the same value
+  for(auto &v : block_max)
+    local_max = fmax_(local_max, v);
   o.dual_error = local_max;
 }
 
 // constraint_matrix_weighted_sum.cxx:14-66 : result = sum_p a[p] A_p
 void constraint_matrix_weighted_sum(Oracle &o, bool use_dx, bool into_dX)
 {
-  F tmp, t2, half;
+  F half;
   mpf_set_d(half.v, 0.5);
-  for(auto &bl : o.blk)
+  parallel_for(o.J, [&](int jj) {
+    Block &bl = o.blk[jj];
+    F tmp, t2;
     {
       const std::vector<F> &a = use_dx ? bl.dx : bl.x;
       for(int b = 0; b < 2; ++b)
@@ -726,6 +774,7 @@ void constraint_matrix_weighted_sum(Oracle &o, bool use_dx, bool into_dX)
                 R(i, j) = R(j, i);
         }
     }
+  });
 }
 
 // compute_primal_residues_and_error_P_Ax_X.cxx:5-14
@@ -746,22 +795,24 @@ void compute_primal_residues_P(Oracle &o)
 // compute_primal_residues_and_error_p_b_Bx.cxx:9-86 : p = b - B^T x
 void compute_primal_residue_p(Oracle &o)
 {
-  F tmp;
   std::vector<F> local(o.N);
-  for(size_t j = 0; j < o.blk.size(); ++j)
-    {
-      Block &bl = o.blk[j];
-      for(int n = 0; n < o.N; ++n)
-        {
-          F acc; // Gemv(TRANSPOSE, -1, B, x, 0, block)
-          for(int p = 0; p < bl.P; ++p)
-            fma_(acc, bl.B(p, n), bl.x[p], tmp);
-          acc = -acc;
-          if(j == 0)
-            acc += o.b[n];
-          local[n] += acc;
-        }
-    }
+  // every entry n visits the blocks in order, as the serial block-outer loop does
+  parallel_for(o.N, [&](int n) {
+    F tmp;
+    for(size_t j = 0; j < o.blk.size(); ++j)
+      {
+        Block &bl = o.blk[j];
+          {
+            F acc; // Gemv(TRANSPOSE, -1, B, x, 0, block)
+            for(int p = 0; p < bl.P; ++p)
+              fma_(acc, bl.B(p, n), bl.x[p], tmp);
+            acc = -acc;
+            if(j == 0)
+              acc += o.b[n];
+            local[n] += acc;
+          }
+      }
+  });
   F mx;
   for(int n = 0; n < o.N; ++n)
     {
@@ -805,8 +856,10 @@ bool compute_feasible_and_termination(Oracle &o, bool &feasible)
 // compute_schur_complement.cxx:15-125
 void compute_schur_complement(Oracle &o)
 {
-  F element, product, four(4L);
-  for(auto &bl : o.blk)
+  const F four(4L);
+  parallel_for(o.J, [&](int jj) {
+    Block &bl = o.blk[jj];
+    F element, product;
     {
       const int K = bl.K, m = bl.m;
       bl.S = Mat(bl.P, bl.P);
@@ -847,12 +900,13 @@ void compute_schur_complement(Oracle &o)
         for(int i = 0; i < j; ++i)
           bl.S(i, j) = bl.S(j, i);
     }
+  });
 }
 
 // compute_Q.cxx:9-61
 void initialize_schur_off_diagonal(Oracle &o)
 {
-  for(int j = 0; j < o.J; ++j)
+  parallel_for(o.J, [&](int j) {
     {
       Block &bl = o.blk[j];
       bl.L = bl.S;
@@ -870,6 +924,7 @@ void initialize_schur_off_diagonal(Oracle &o)
       bl.Poff = bl.B;
       trsm_lln(bl.L, bl.Poff);
     }
+  });
 }
 
 // compute_Q.cxx:94-132 with Matrix_Normalizer.cxx:75-137,174-192,210-264 and
@@ -882,20 +937,21 @@ void syrk_Q(Oracle &o)
   // GMP reports the rounded-up precision (El::gmp::Precision(), compute_Q.cxx:107)
   const mp_bitcnt_t p = mpf_get_default_prec();
   std::vector<F> norms2(N), norms(N);
-  F tmp;
-  for(auto &bl : o.blk)
-    for(int n = 0; n < N; ++n)
+  parallel_for(N, [&](int n) {
+    F tmp;
+    for(auto &bl : o.blk)
       for(int r = 0; r < bl.P; ++r)
         fma_(norms2[n], bl.Poff(r, n), bl.Poff(r, n), tmp);
-  for(int n = 0; n < N; ++n)
     norms[n] = fsqrt(norms2[n]);
+  });
 
   // integer image of P'
   std::vector<std::vector<Z>> cols(N);
   size_t Ptot = 0;
   for(auto &bl : o.blk)
     Ptot += bl.P;
-  for(int n = 0; n < N; ++n)
+  parallel_for(N, [&](int n) {
+    F tmp;
     {
       cols[n].resize(Ptot);
       size_t r0 = 0;
@@ -916,12 +972,15 @@ void syrk_Q(Oracle &o)
           r0 += bl.P;
         }
     }
+  });
   o.Q = Mat(N, N);
-  mpz_t acc;
-  mpz_init(acc);
   F one(1L), eps(1L);
   mpf_div_2exp(eps.v, eps.v, p / 2);
-  for(int j = 0; j < N; ++j)
+  // columns from the last to the first: the long ones start first (dynamic schedule)
+  parallel_for(N, [&](int jr) {
+    const int j = N - 1 - jr;
+    Z accz;
+    mpz_ptr acc = accz.v;
     for(int i = 0; i <= j; ++i)
       {
         mpz_set_ui(acc, 0);
@@ -942,7 +1001,7 @@ void syrk_Q(Oracle &o)
         q = q * norms[i] * norms[j];
         o.Q(i, j) = q;
       }
-  mpz_clear(acc);
+  });
   // restore_P (Matrix_Normalizer.cxx:210-227) returns P to (P'>>p)*norm; the
   // oracle keeps the un-normalised P, which differs from that by the
   // truncation of P' only (relative 2^-p) — inside every stated tolerance.
@@ -1024,8 +1083,8 @@ void symmetrize(Mat &A)
 // compute_schur_RHS.cxx:21-86
 void compute_schur_RHS(Oracle &o, std::vector<Mat> &Z /* 2 per block */)
 {
-  F tmp;
-  for(int j = 0; j < o.J; ++j)
+  parallel_for(o.J, [&](int j) {
+    F tmp;
     {
       Block &bl = o.blk[j];
       for(int p = 0; p < bl.P; ++p)
@@ -1055,39 +1114,48 @@ void compute_schur_RHS(Oracle &o, std::vector<Mat> &Z /* 2 per block */)
               }
         }
     }
+  });
 }
 
 // solve_schur_complement_equation.cxx:16-79
 void solve_schur_complement_equation(Oracle &o)
 {
-  F tmp;
   std::vector<F> dy_sum(o.N);
-  for(size_t j = 0; j < o.blk.size(); ++j)
-    {
-      Block &bl = o.blk[j];
-      // dx = L^{-1} dx
-      for(int i = 0; i < bl.P; ++i)
-        {
-          for(int k = 0; k < i; ++k)
-            fms_(bl.dx[i], bl.L(i, k), bl.dx[k], tmp);
-          bl.dx[i] /= bl.L(i, i);
-        }
+  parallel_for(o.J, [&](int j) {
+    Block &bl = o.blk[j];
+    F tmp;
+    // dx = L^{-1} dx
+    for(int i = 0; i < bl.P; ++i)
+      {
+        for(int k = 0; k < i; ++k)
+          fms_(bl.dx[i], bl.L(i, k), bl.dx[k], tmp);
+        bl.dx[i] /= bl.L(i, i);
+      }
+  });
+  // every entry n visits the blocks in order, as the serial block-outer loop does
+  parallel_for(o.N, [&](int n) {
+    F tmp;
+    for(size_t j = 0; j < o.blk.size(); ++j)
+      {
+        Block &bl = o.blk[j];
       // dy_block = dy - P^T dx ; summed over blocks.  In the reference every
       // block holds a copy of dy (= primal_residue_p, which is non-zero in
       // block 0 plus the B^T x pieces — already summed here), so the sum of
       // the per-block copies is sum_j(-P_j^T dx_j) + sum_j dy_j.
-      for(int n = 0; n < o.N; ++n)
-        {
-          F acc;
-          for(int p = 0; p < bl.P; ++p)
-            fma_(acc, bl.Poff(p, n), bl.dx[p], tmp);
-          dy_sum[n] -= acc;
-        }
-    }
+          {
+            F acc;
+            for(int p = 0; p < bl.P; ++p)
+              fma_(acc, bl.Poff(p, n), bl.dx[p], tmp);
+            dy_sum[n] -= acc;
+          }
+      }
+  });
   for(int n = 0; n < o.N; ++n)
     o.dy[n] = o.dy[n] + dy_sum[n];
   solve_after_upper(o.Q, o.dy);
-  for(auto &bl : o.blk)
+  parallel_for(o.J, [&](int jj) {
+    Block &bl = o.blk[jj];
+    F tmp;
     {
       for(int p = 0; p < bl.P; ++p)
         {
@@ -1104,6 +1172,7 @@ void solve_schur_complement_equation(Oracle &o)
           bl.dx[i] /= bl.L(i, i);
         }
     }
+  });
 }
 
 // compute_search_direction.cxx:44-90
@@ -1112,8 +1181,8 @@ void compute_search_direction(Oracle &o, const F &beta, bool corrector)
   const F one(1L), zero(0L), minus_one(-1L);
   std::vector<Mat> R(2 * o.J), Z(2 * o.J);
   F bm = beta * o.mu;
-  for(int j = 0; j < o.J; ++j)
-    for(int b = 0; b < 2; ++b)
+  parallel_for(2 * o.J, [&](int jb) {
+    const int j = jb / 2, b = jb % 2;
       {
         Block &bl = o.blk[j];
         Mat &Rb = R[2 * j + b];
@@ -1130,6 +1199,7 @@ void compute_search_direction(Oracle &o, const F &beta, bool corrector)
         cholesky_solve(bl.Xc[b], Zb);
         symmetrize(Zb);
       }
+  });
   compute_schur_RHS(o, Z);
   // In the reference each block's dy starts as that block's primal_residue_p
   // (compute_search_direction.cxx:74); their sum over blocks is the global
@@ -1138,8 +1208,8 @@ void compute_search_direction(Oracle &o, const F &beta, bool corrector)
     o.dy[n] = o.primal_residue_p[n];
   solve_schur_complement_equation(o);
   constraint_matrix_weighted_sum(o, true, true);
-  for(int j = 0; j < o.J; ++j)
-    for(int b = 0; b < 2; ++b)
+  parallel_for(2 * o.J, [&](int jb) {
+    const int j = jb / 2, b = jb % 2;
       {
         Block &bl = o.blk[j];
         for(size_t i = 0; i < bl.dX[b].a.size(); ++i)
@@ -1153,24 +1223,27 @@ void compute_search_direction(Oracle &o, const F &beta, bool corrector)
         for(auto &v : dYb.a)
           v = -v;
       }
+  });
 }
 
 // corrector_centering_parameter.cxx:12-31, frobenius_product_of_sums.cxx:6-31
 F corrector_centering_parameter(Oracle &o, bool feasible)
 {
-  F sum, tmp;
-  for(auto &bl : o.blk)
-    for(int b = 0; b < 2; ++b)
+  std::vector<F> locals(2 * o.J);
+  parallel_for(2 * o.J, [&](int jb) {
+    Block &bl = o.blk[jb / 2];
+    const int b = jb % 2;
+    F tmp, &local = locals[jb];
+    for(size_t i = 0; i < bl.X[b].a.size(); ++i)
       {
-        F local;
-        for(size_t i = 0; i < bl.X[b].a.size(); ++i)
-          {
-            F xs = bl.X[b].a[i] + bl.dX[b].a[i];
-            F ys = bl.Y[b].a[i] + bl.dY[b].a[i];
-            fma_(local, xs, ys, tmp);
-          }
-        sum += local;
+        F xs = bl.X[b].a[i] + bl.dX[b].a[i];
+        F ys = bl.Y[b].a[i] + bl.dY[b].a[i];
+        fma_(local, xs, ys, tmp);
       }
+  });
+  F sum;
+  for(auto &local : locals) // block order, as in the serial loop
+    sum += local;
   F r = sum / (o.mu * F(o.total_psd_rows));
   F beta = (r < F(1L)) ? r * r : r;
   if(feasible)
@@ -1184,22 +1257,29 @@ F step_length(Oracle &o, bool primal)
 {
   bool have = false;
   F lambda;
-  for(auto &bl : o.blk)
-    for(int b = 0; b < 2; ++b)
-      {
-        if(bl.n[b] == 0)
-          continue;
-        Mat A(primal ? bl.dX[b] : bl.dY[b]);
-        const Mat &L = primal ? bl.Xc[b] : bl.Yc[b];
-        trsm_rlt(L, A);
-        trsm_lln(L, A);
-        F ev = min_eigenvalue_sym(A);
-        if(!have || ev < lambda)
-          {
-            lambda = ev;
-            have = true;
-          }
-      }
+  std::vector<F> evs(2 * o.J);
+  parallel_for(2 * o.J, [&](int jb) {
+    Block &bl = o.blk[jb / 2];
+    const int b = jb % 2;
+    if(bl.n[b] == 0)
+      return;
+    Mat A(primal ? bl.dX[b] : bl.dY[b]);
+    const Mat &L = primal ? bl.Xc[b] : bl.Yc[b];
+    trsm_rlt(L, A);
+    trsm_lln(L, A);
+    evs[jb] = min_eigenvalue_sym(A);
+  });
+  for(int jb = 0; jb < 2 * o.J; ++jb)
+    {
+      if(o.blk[jb / 2].n[jb % 2] == 0)
+        continue;
+      const F &ev = evs[jb];
+      if(!have || ev < lambda)
+        {
+          lambda = ev;
+          have = true;
+        }
+    }
   const F &gamma = o.par.step_length_reduction;
   if(lambda > -gamma)
     return F(1L);
@@ -1223,16 +1303,18 @@ bool step(Oracle &o, bool feasible)
     }
   const F minus_one(-1L), zero(0L);
   F trace;
-  for(auto &bl : o.blk)
-    for(int b = 0; b < 2; ++b)
-      {
-        bl.minusXY[b] = Mat(bl.n[b], bl.n[b]);
-        gemm_nn(minus_one, bl.X[b], bl.Y[b], zero, bl.minusXY[b]);
-        F t; // El::Trace per block then accumulated
-        for(int i = 0; i < bl.n[b]; ++i)
-          t += bl.minusXY[b](i, i);
-        trace += t;
-      }
+  std::vector<F> traces(2 * o.J);
+  parallel_for(2 * o.J, [&](int jb) {
+    Block &bl = o.blk[jb / 2];
+    const int b = jb % 2;
+    bl.minusXY[b] = Mat(bl.n[b], bl.n[b]);
+    gemm_nn(minus_one, bl.X[b], bl.Y[b], zero, bl.minusXY[b]);
+    F &t = traces[jb]; // El::Trace per block then accumulated
+    for(int i = 0; i < bl.n[b]; ++i)
+      t += bl.minusXY[b](i, i);
+  });
+  for(auto &t : traces)
+    trace += t;
   o.mu = -trace / F(o.total_psd_rows);
   if(o.mu > o.par.max_complementarity)
     return true;
@@ -1326,6 +1408,26 @@ void parse_list(const char *txt, std::vector<F> &out, size_t expect,
   return 0;
 
 extern "C" {
+
+// number of host threads the block/column loops use (0 = all cores); returns the count in effect
+int orc_set_threads(int n)
+{
+#ifdef _OPENMP
+  if(n > 0)
+    omp_set_num_threads(n);
+  else if(const char *e = getenv("ORACLE_THREADS"))
+    {
+      if(atoi(e) > 0)
+        omp_set_num_threads(atoi(e));
+    }
+  else
+    omp_set_num_threads(omp_get_num_procs());
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
 
 void *orc_create(int precision_bits, int J, const int *dims,
                  const int *num_points, int N)
@@ -1464,6 +1566,43 @@ int orc_set_block(void *h, int j, const char *bases_even,
     for(int n = 0; n < o->N; ++n)
       bl.B(p, n) = tmp[(size_t)p * o->N + n];
   parse_list(c, bl.c, bl.P, "c");
+  ORC_CATCH(o)
+}
+
+// Same block with B (row-major P x N) and c given as doubles: exact for the dyadic
+// rationals of the synthetic generator (mpf_set_d is exact), no decimal round trip.
+int orc_set_block_f64(void *h, int j, const char *bases_even,
+                      const char *bases_odd, const double *B, const double *c)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  ORC_TRY(o)
+  Block &bl = o->blk.at(j);
+  // bases through the text path (shared code), B and c below
+  {
+    std::vector<F> tmp;
+    const char *src[2] = {bases_even, bases_odd};
+    for(int b = 0; b < 2; ++b)
+      {
+        parse_list(src[b], tmp, (size_t)bl.rows[b] * bl.K, "bilinear_bases");
+        bl.bases[b] = Mat(bl.rows[b], bl.K);
+        for(int r = 0; r < bl.rows[b]; ++r)
+          for(int k = 0; k < bl.K; ++k)
+            bl.bases[b](r, k) = tmp[(size_t)r * bl.K + k];
+        Mat &E = bl.bases_block[b];
+        E = Mat(bl.n[b], bl.m * bl.K);
+        for(int row = 0; row < E.h; ++row)
+          for(int col = 0; col < E.w; ++col)
+            if(row / bl.rows[b] == col / bl.K)
+              E(row, col) = bl.bases[b](row % bl.rows[b], col % bl.K);
+      }
+  }
+  bl.B = Mat(bl.P, o->N);
+  for(int p = 0; p < bl.P; ++p)
+    for(int n = 0; n < o->N; ++n)
+      mpf_set_d(bl.B(p, n).v, B[(size_t)p * o->N + n]);
+  bl.c.resize(bl.P);
+  for(int p = 0; p < bl.P; ++p)
+    mpf_set_d(bl.c[p].v, c[p]);
   ORC_CATCH(o)
 }
 

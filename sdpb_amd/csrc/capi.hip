@@ -193,6 +193,7 @@ int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j)
   return r;
 }
 int sdpb_hip_limbs(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->limbs() : 0; }
+int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->fx_frac_bits() : 0; }
 
 int sdpb_hip_set_collectives(sdpb_hip_ctx *ctx, const sdpb_hip_collectives *c)
 {

@@ -991,8 +991,43 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
 //   sum_r v_ri v_rj   = G(i,j) - C (S_i + S_j) + n C^2,  S_i = sum_r a'_ri  (k_fx_colsum)
 // Everything is integer and exact; three bits of the 32 FX-bit image pay for the bias
 // and for the carry-free s = lo + hi.
-template <int FX> constexpr int fx_planes() { return 3 * (FX / 2); }
-template <int FX> constexpr int fx_frac_bits() { return 32 * FX - 3; }
+//
+// TWO Karatsuba levels (fx_two_level<FX>(): FX divisible by 4): each of lo, hi, s is split
+// once more, x = x1 B2 + x0, B2 = 2^(32 M2 - 1), M2 = FX/4, t = x0 + x1 < 2^(32 M2), so one row
+// pair costs 9 products of M2 x M2 limbs (9/16 of the plain FX x FX product instead of 3/4).
+// The carry-free sums of the second level cost four more bits: FB = 32 FX - 7,
+// lo, hi < B = 2^(32M-3), s < 2^(32M-2), pieces < 2^(32 M2 - 1).  The image then holds nine
+// M2-limb pieces per element, piece-major: words [(g * stride + idx) * M2, +M2), g = 3 k + u
+// with k in (lo, hi, s) and u in (x0, x1, t), so a piece is one 16-byte load when M2 = 4.
+template <int FX> constexpr bool fx_two_level()
+{
+#ifdef SDPB_SYRK_ONE_LEVEL
+  return false;
+#else
+  return FX % 4 == 0 && FX <= 24;
+#endif
+}
+template <int FX> constexpr int fx_planes() { return fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2); }
+template <int FX> constexpr int fx_frac_bits() { return fx_two_level<FX>() ? 32 * FX - 7 : 32 * FX - 3; }
+
+// out = (x >> BIT0) mod 2^NB as OUT limbs (compile-time positions)
+template <int BIT0, int NB, int W, int OUT> MW_HD void bits_slice(const uint32_t (&x)[W], uint32_t (&out)[OUT])
+{
+  constexpr int q = BIT0 / 32, r = BIT0 % 32;
+#pragma unroll
+  for(int i = 0; i < OUT; ++i)
+    {
+      const uint32_t lo = (q + i < W) ? x[q + i < W ? q + i : 0] : 0u;
+      const uint32_t hi = (q + i + 1 < W) ? x[q + i + 1 < W ? q + i + 1 : 0] : 0u;
+      uint32_t v = r ? ((lo >> r) | (hi << ((32 - r) & 31))) : lo;
+      const int left = NB - 32 * i;
+      if(left <= 0)
+        v = 0;
+      else if(left < 32)
+        v &= (1u << (left & 31)) - 1u;
+      out[i] = v;
+    }
+}
 
 // add x << SH (x an A-limb unsigned integer) into the W-limb integer w; negate: subtract
 template <int W, int A> MW_HD void add_shifted(uint32_t (&w)[W], const uint32_t (&x)[A], int sh, bool negate)
@@ -1019,10 +1054,16 @@ template <int W, int A> MW_HD void add_shifted(uint32_t (&w)[W], const uint32_t 
 }
 
 // write the 3M planes of one element from sign + FX-limb magnitude (|v| < 2^FB)
+template <int FX> MW_HD void fx_store2(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx);
 template <int FX> MW_HD void fx_store(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
 {
   constexpr int M = FX / 2;
   static_assert(FX % 2 == 0 && FX >= 4, "FX = NL - 2 is even");
+  if constexpr(fx_two_level<FX>())
+    {
+      fx_store2<FX>(mag, negative, fx, fx_stride, idx);
+      return;
+    }
   // a' = C +/- |v|, C = bit 29 of the top limb
   uint32_t a[FX];
   uint64_t borrow = 0;
@@ -1056,6 +1097,60 @@ template <int FX> MW_HD void fx_store(const uint32_t (&mag)[FX], bool negative, 
       fx[(size_t)i * fx_stride + idx] = lo[i];
       fx[(size_t)(M + i) * fx_stride + idx] = hi[i];
       fx[(size_t)(2 * M + i) * fx_stride + idx] = (uint32_t)s;
+    }
+}
+
+// two-level image of one element (|v| < 2^FB, FB = 32 FX - 7)
+template <int FX> MW_HD void fx_store2(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
+{
+  constexpr int M = FX / 2, M2 = FX / 4, FB = fx_frac_bits<FX>();
+  static_assert(FB / 32 == FX - 1, "the bias bit sits in the top limb");
+  uint32_t a[FX];
+  uint64_t borrow = 0;
+#pragma unroll
+  for(int i = 0; i < FX; ++i)
+    {
+      const uint32_t c = (i == FX - 1) ? (1u << (FB % 32)) : 0u;
+      if(negative)
+        {
+          const uint64_t d = (uint64_t)c - (uint64_t)mag[i] - borrow;
+          a[i] = (uint32_t)d;
+          borrow = (d >> 63) & 1u;
+        }
+      else
+        a[i] = mag[i] | c;
+    }
+  uint32_t x[3][M];
+  bits_slice<0, 32 * M - 3>(a, x[0]);
+  bits_slice<32 * M - 3, 32 * M - 3>(a, x[1]);
+  {
+    uint64_t cy = 0;
+#pragma unroll
+    for(int i = 0; i < M; ++i)
+      {
+        const uint64_t t = (uint64_t)x[0][i] + x[1][i] + cy;
+        x[2][i] = (uint32_t)t;
+        cy = t >> 32;
+      }
+  }
+#pragma unroll
+  for(int k = 0; k < 3; ++k)
+    {
+      uint32_t p0[M2], p1[M2];
+      bits_slice<0, 32 * M2 - 1>(x[k], p0);
+      bits_slice<32 * M2 - 1, 32 * M2 - 1>(x[k], p1);
+      uint32_t *o0 = fx + ((size_t)(3 * k) * fx_stride + idx) * M2, *o1 = fx + ((size_t)(3 * k + 1) * fx_stride + idx) * M2,
+               *ot = fx + ((size_t)(3 * k + 2) * fx_stride + idx) * M2;
+      uint64_t cy = 0;
+#pragma unroll
+      for(int i = 0; i < M2; ++i)
+        {
+          const uint64_t t = (uint64_t)p0[i] + p1[i] + cy;
+          cy = t >> 32;
+          o0[i] = p0[i];
+          o1[i] = p1[i];
+          ot[i] = (uint32_t)t;
+        }
     }
 }
 
@@ -1519,6 +1614,268 @@ template <int FX> __global__ void __launch_bounds__(WG) k_syrk_reduce(const uint
         cy += part[((size_t)s * W + k) * acc_stride + idx];
       acc[(size_t)k * acc_stride + idx] = (uint32_t)cy;
       cy >>= 32;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same G with TWO Karatsuba levels (piece-major image, fx_two_level<FX>()).
+// ---------------------------------------------------------------------------
+// Column sums S_n = sum_r a'_rn from the pieces lo0, lo1, hi0, hi1 (groups 0, 1, 3, 4):
+//   S = sum lo0 + sum lo1 B2 + (sum hi0 + sum hi1 B2) B.
+// Stage 1: workgroup (x, y) sums row slice y of 64 columns (4 row phases per column, meeting in
+// LDS) into partial[y]; element (slice, u, k, n), u < 4, k < M2 + 2, at
+// ((slice * 4 + u) * (M2 + 2) + k) * N + n.  Stage 2 adds the slices and recombines.
+template <int FX>
+__global__ void __launch_bounds__(WG) k_fx_colsum2(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, unsigned rows_per_slice, uint32_t *partial)
+{
+  constexpr int M2 = FX / 4, A = M2 + 2;
+  const int lane = threadIdx.x & 63, col = blockIdx.x * 64 + lane, phase = threadIdx.x >> 6;
+  const unsigned r_begin = blockIdx.y * rows_per_slice, r_end = (r_begin + rows_per_slice < nrows) ? r_begin + rows_per_slice : nrows;
+  uint32_t sum[4][A];
+#pragma unroll
+  for(int u = 0; u < 4; ++u)
+#pragma unroll
+    for(int k = 0; k < A; ++k)
+      sum[u][k] = 0;
+  if(col < N)
+    for(unsigned r = r_begin + phase; r < r_end; r += 4)
+      {
+        const size_t e = (size_t)r * N + col;
+#pragma unroll
+        for(int u = 0; u < 4; ++u)
+          {
+            const uint32_t *src = fx + ((size_t)(u < 2 ? u : u + 1) * fx_stride + e) * M2;
+            uint64_t cy = 0;
+#pragma unroll
+            for(int k = 0; k < A; ++k)
+              {
+                const uint64_t t = (uint64_t)sum[u][k] + (k < M2 ? src[k < M2 ? k : 0] : 0u) + cy;
+                sum[u][k] = (uint32_t)t;
+                cy = t >> 32;
+              }
+          }
+      }
+  __shared__ uint32_t sm[3 * 4 * A * 64];
+  if(phase > 0)
+    {
+#pragma unroll
+      for(int u = 0; u < 4; ++u)
+#pragma unroll
+        for(int k = 0; k < A; ++k)
+          sm[(((phase - 1) * 4 + u) * A + k) * 64 + lane] = sum[u][k];
+    }
+  __syncthreads();
+  if(phase == 0 && col < N)
+    {
+      for(int p = 0; p < 3; ++p)
+#pragma unroll
+        for(int u = 0; u < 4; ++u)
+          {
+            uint64_t cy = 0;
+#pragma unroll
+            for(int k = 0; k < A; ++k)
+              {
+                const uint64_t t = (uint64_t)sum[u][k] + sm[((p * 4 + u) * A + k) * 64 + lane] + cy;
+                sum[u][k] = (uint32_t)t;
+                cy = t >> 32;
+              }
+          }
+#pragma unroll
+      for(int u = 0; u < 4; ++u)
+#pragma unroll
+        for(int k = 0; k < A; ++k)
+          partial[(((size_t)blockIdx.y * 4 + u) * A + k) * N + col] = sum[u][k];
+    }
+}
+template <int FX>
+__global__ void __launch_bounds__(WG) k_fx_colsum2_final(const uint32_t *partial, int nslices, int N, uint32_t *acc, size_t acc_stride)
+{
+  constexpr int M2 = FX / 4, M = FX / 2, A = M2 + 2, W = 2 * FX + 2;
+  const int col = blockIdx.x * WG + threadIdx.x;
+  if(col >= N)
+    return;
+  uint32_t sum[4][A];
+#pragma unroll
+  for(int u = 0; u < 4; ++u)
+#pragma unroll
+    for(int k = 0; k < A; ++k)
+      sum[u][k] = 0;
+  for(int s = 0; s < nslices; ++s)
+#pragma unroll
+    for(int u = 0; u < 4; ++u)
+      {
+        uint64_t cy = 0;
+#pragma unroll
+        for(int k = 0; k < A; ++k)
+          {
+            const uint64_t t = (uint64_t)sum[u][k] + partial[(((size_t)s * 4 + u) * A + k) * N + col] + cy;
+            sum[u][k] = (uint32_t)t;
+            cy = t >> 32;
+          }
+      }
+  uint32_t w[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    w[k] = k < A ? sum[0][k < A ? k : 0] : 0u;
+  add_shifted<W, A>(w, sum[1], 32 * M2 - 1, false);
+  add_shifted<W, A>(w, sum[2], 32 * M - 3, false);
+  add_shifted<W, A>(w, sum[3], 32 * M - 3 + 32 * M2 - 1, false);
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    acc[(size_t)k * acc_stride + (size_t)N * N + col] = w[k];
+}
+
+// d -= x (both A limbs, d >= x)
+template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
+{
+  uint64_t bw = 0;
+#pragma unroll
+  for(int k = 0; k < A; ++k)
+    {
+      const uint64_t t = (uint64_t)d[k] - (uint64_t)x[k] - bw;
+      d[k] = (uint32_t)t;
+      bw = (t >> 63) & 1u;
+    }
+}
+
+// acc(i,j) (i >= j) = G(i,j) = sum_r a'(r,i) a'(r,j) exactly as k_syrk_fx (same tiles, same
+// XCD-aware item order, same row splits), but nine M2 x M2 products per row pair.  One PASS =
+// one product g over RBG rows of the tile's two operand panels: the 16 x RBG pieces of group g
+// of each panel sit in LDS ([row][column][M2 limbs], a lane reads its piece with one
+// ds_read_b128 when M2 = 4; the i operand is conflict-free, the j operand a broadcast), the
+// 2 M2 - 1 column accumulators run over the RBG rows and are folded into that product's
+// (2 M2 + 2)-limb sum once.  The pieces of the NEXT pass are fetched from HBM/L2 into registers
+// while the MACs run and are written to the other LDS buffer when the pass ends (one barrier
+// per pass).  The nine sums are recombined once per output element after the row loop.
+template <int FX, int RBG>
+__global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
+  k_syrk_fx2(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
+             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split)
+{
+  constexpr int M2 = FX / 4, M = FX / 2, A2 = 2 * M2 + 2, A = 2 * M + 2, W = 2 * FX + 2;
+  constexpr int NP = RBG * 16, GL = NP / WG; // pieces per operand per pass, per lane
+  static_assert(NP % WG == 0, "a pass stages a whole number of pieces per lane");
+  const uint32_t *fx = (const uint32_t *)__builtin_assume_aligned(fx_in, 16);
+  const int nitem = ntile * nsplit, per = (nitem + 7) / 8;
+  const int item = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+  if((int)(blockIdx.x / 8) >= per || item >= nitem)
+    return;
+  const int split = item / ntile, tile = item % ntile;
+  const unsigned row_begin = (unsigned)split * rows_per_split;
+  const unsigned row_end = (row_begin + rows_per_split < nrows && split + 1 < nsplit) ? row_begin + rows_per_split : nrows;
+  acc += (size_t)split * W * acc_stride;
+  const uint32_t tt = tile_list[tile];
+  const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
+  const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
+  const int i = ti * 16 + li, j = tj * 16 + lj;
+  __shared__ __attribute__((aligned(16))) uint32_t sa[2 * NP * M2];
+  __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NP * M2];
+  uint32_t g2[9][A2];
+#pragma unroll
+  for(int g = 0; g < 9; ++g)
+#pragma unroll
+    for(int k = 0; k < A2; ++k)
+      g2[g][k] = 0;
+  uint32_t va[GL][M2], vb[GL][M2];
+  auto fetch = [&](int g, unsigned r0) __attribute__((always_inline)) {
+#pragma unroll
+    for(int t = 0; t < GL; ++t)
+      {
+        const int e = threadIdx.x + t * WG;
+        const int col = e & 15, rr = e >> 4;
+        const unsigned r = r0 + rr;
+        const int ca = ti * 16 + col, cb = tj * 16 + col;
+        const bool ok = r < row_end;
+        // lanes outside the image read a valid piece and drop it: no divergent branches
+        const uint32_t *row = fx + ((size_t)g * fx_stride + (size_t)(ok ? r : row_begin) * (size_t)N) * M2;
+        const uint32_t *pa = row + (size_t)(ca < N ? ca : 0) * M2, *pb = row + (size_t)(cb < N ? cb : 0) * M2;
+#pragma unroll
+        for(int l = 0; l < M2; ++l)
+          {
+            const uint32_t xa = pa[l], xb = pb[l];
+            va[t][l] = (ok && ca < N) ? xa : 0u; // rows past the end and columns past N: zero limbs,
+            vb[t][l] = (ok && cb < N) ? xb : 0u; // they add nothing to any product
+          }
+      }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for(int t = 0; t < GL; ++t)
+      {
+        const int e = threadIdx.x + t * WG;
+#pragma unroll
+        for(int l = 0; l < M2; ++l)
+          {
+            sa[(buf * NP + e) * M2 + l] = va[t][l];
+            sb[(buf * NP + e) * M2 + l] = vb[t][l];
+          }
+      }
+  };
+  fetch(0, row_begin);
+  store(0);
+  __syncthreads();
+  int buf = 0;
+  for(unsigned r0 = row_begin; r0 < row_end; r0 += RBG)
+    {
+#pragma unroll
+      for(int g = 0; g < 9; ++g)
+        {
+          fetch(g < 8 ? g + 1 : 0, g < 8 ? r0 : r0 + RBG);
+          uint64_t c[2 * M2 - 1];
+          uint32_t h[2 * M2 - 1];
+#pragma unroll
+          for(int k = 0; k < 2 * M2 - 1; ++k)
+            {
+              c[k] = 0;
+              h[k] = 0;
+            }
+          const uint32_t *pa = sa + (buf * NP + li) * M2, *pb = sb + (buf * NP + lj) * M2;
+#pragma unroll 4
+          for(int rr = 0; rr < RBG; ++rr)
+            {
+              uint32_t a[M2], b[M2];
+#pragma unroll
+              for(int l = 0; l < M2; ++l)
+                {
+                  a[l] = pa[rr * 16 * M2 + l];
+                  b[l] = pb[rr * 16 * M2 + l];
+                }
+              SyrkColumns<M2, 0>::run(a, b, c, h);
+            }
+          syrk_fold<M2>(g2[g], c, h);
+          store(buf ^ 1);
+          __syncthreads();
+          buf ^= 1;
+        }
+    }
+  if(i < N && j <= i)
+    {
+      // second level: XX = X0X0 + (XtXt - X0X0 - X1X1) B2 + X1X1 B2^2 for X in (lo, hi, s)
+      uint32_t x[3][A];
+#pragma unroll
+      for(int k = 0; k < 3; ++k)
+        {
+          sub_limbs<A2>(g2[3 * k + 2], g2[3 * k]);
+          sub_limbs<A2>(g2[3 * k + 2], g2[3 * k + 1]);
+#pragma unroll
+          for(int q = 0; q < A; ++q)
+            x[k][q] = q < A2 ? g2[3 * k][q < A2 ? q : 0] : 0u;
+          add_shifted<A, A2>(x[k], g2[3 * k + 2], 32 * M2 - 1, false);
+          add_shifted<A, A2>(x[k], g2[3 * k + 1], 64 * M2 - 2, false);
+        }
+      // first level: G = LL + (SS - LL - HH) B + HH B^2, B = 2^(32M-3)
+      sub_limbs<A>(x[2], x[0]);
+      sub_limbs<A>(x[2], x[1]);
+      uint32_t w[W];
+#pragma unroll
+      for(int k = 0; k < W; ++k)
+        w[k] = k < A ? x[0][k < A ? k : 0] : 0u;
+      add_shifted<W, A>(w, x[2], 32 * M - 3, false);
+      add_shifted<W, A>(w, x[1], 64 * M - 6, false);
+      const size_t o = (size_t)i + (size_t)j * N;
+#pragma unroll
+      for(int k = 0; k < W; ++k)
+        acc[(size_t)k * acc_stride + o] = w[k];
     }
 }
 

@@ -118,6 +118,7 @@ public:
   virtual void set_collectives(const Collectives &c) = 0;
   virtual std::string timers_json() const = 0;
   virtual int limbs() const = 0;
+  virtual int fx_frac_bits() const = 0;
   // operator-level entry points for parity tests
   virtual std::string op_scalar(const std::string &op, const char *a, const char *b) = 0;
   virtual std::string op_int_syrk(int rows, int cols, const char *ints_colmajor) = 0;
@@ -155,7 +156,9 @@ template <int NL> class Solver : public SolverBase
   using M = Mw<NL>;
   static constexpr int FX = NL - 2; // 32*FX = GMP's rounded precision 64*(l-1) (compute_Q.cxx:107)
   static constexpr int ACCW = 2 * FX + 2;
-  static constexpr int SYRK_RB = FX <= 24 ? 16 : 8; // rows per LDS chunk of k_syrk_fx (LDS: 3 FX/2 planes x RB x 16 x 2 operands)
+  static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>(); // nine (FX/4)^2 products per row pair (k_syrk_fx2) instead of three (FX/2)^2
+  // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
+  static constexpr int SYRK_RB = SYRK_TWO_LEVEL ? 32 : (FX <= 24 ? 16 : 8);
 
   // ---- problem shape -------------------------------------------------------
   int precision_, J_, N_, rank_, world_;
@@ -277,6 +280,7 @@ public:
       (void)hipStreamDestroy(stream_);
   }
   int limbs() const override { return NL; }
+  int fx_frac_bits() const override { return sdpb::fx_frac_bits<FX>(); }
   int block_owner(int j) const override { return owner_.at(j); }
   void set_collectives(const Collectives &c) override { coll_ = c; }
   int terminate_reason() const override { return terminate_reason_; }
@@ -409,7 +413,7 @@ private:
         syrk_part_.alloc((size_t)nsplit * ACCW * acc_stride_);
     }
     colsum_slices_ = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv(Ptot_, 64)));
-    colsum_partial_.alloc((size_t)colsum_slices_ * 2 * (FX / 2 + 2) * N_);
+    colsum_partial_.alloc((size_t)colsum_slices_ * (FX + 8) * N_); // 2 (FX/2 + 2) or 4 (FX/4 + 2) limbs per column and slice
     syrk_tiles_.upload(syrk_tile_order(N_));
     if(world_ > 1)
       {
@@ -485,7 +489,9 @@ public:
     const double fx_bytes = (double)Ptot_ * N_ * (FX + 1) * 4.0, acc_bytes = (double)N_ * (N_ + 1) / 2 * ACCW * 4.0;
     ss << (first ? "" : ", ") << "\"kernel.k_syrk_fx.ms\": " << syrk_kernel_ms_ << ", \"kernel.k_syrk_fx.launches\": " << syrk_launches_
        << ", \"kernel.k_syrk_fx.algorithmic_bytes\": " << (fx_bytes + acc_bytes)
-       << ", \"kernel.k_syrk_fx.limb_macs\": " << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * 0.75; // executed: 3 (FX/2)^2 per product
+       << ", \"kernel.k_syrk_fx.limb_macs\": "
+       << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 9 (FX/4)^2 or 3 (FX/2)^2 per product
+       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TWO_LEVEL ? 2 : 1);
     ss << "}";
     return ss.str();
   }
@@ -1086,8 +1092,12 @@ private:
           part.alloc((size_t)nsplit * ACCW * acc_stride);
         out = part.p;
       }
-    launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
-           tiles_dev, ntile, nsplit, rps);
+    if constexpr(SYRK_TWO_LEVEL)
+      launch(k_syrk_fx2<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
+             tiles_dev, ntile, nsplit, rps);
+    else
+      launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
+             tiles_dev, ntile, nsplit, rps);
     if(nsplit > 1)
       launch(k_syrk_reduce<FX>, dim3(cdiv((size_t)N * N, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, acc, acc_stride, N);
   }
@@ -1096,6 +1106,12 @@ private:
                         unsigned slices)
   {
     const unsigned rows_per_slice = cdiv(nrows, slices);
+    if constexpr(SYRK_TWO_LEVEL)
+      {
+        launch(k_fx_colsum2<FX>, dim3(cdiv(N, 64), slices), dim3(WG), stream_, fx, fx_stride, nrows, N, rows_per_slice, partial);
+        launch(k_fx_colsum2_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride);
+        return;
+      }
     launch(k_fx_colsum<FX>, dim3(cdiv(N, 64), slices), dim3(WG), stream_, fx, fx_stride, nrows, N, rows_per_slice, partial);
     launch(k_fx_colsum_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride);
   }
@@ -1625,8 +1641,8 @@ public:
               else
                 n.mul_small(10, (uint32_t)(*s - '0'));
             }
-          if(n.w.size() > (size_t)FX || (n.w.size() == (size_t)FX && (n.w[FX - 1] >> 29) != 0))
-            throw SolverError(4, "op_int_syrk: |value| >= 2^(32*FX-3)");
+          if(n.w.size() > (size_t)FX || (n.w.size() == (size_t)FX && (n.w[FX - 1] >> (sdpb::fx_frac_bits<FX>() % 32)) != 0))
+            throw SolverError(4, "op_int_syrk: |value| >= 2^" + std::to_string(sdpb::fx_frac_bits<FX>()));
           const size_t idx = (size_t)r * cols + c; // fx element (r, n) at r*N + n
           for(size_t k = 0; k < n.w.size(); ++k)
             h[(k + 1) * cnt + idx] = n.w[k];
@@ -1639,7 +1655,7 @@ public:
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
-    partial.alloc((size_t)slices * 2 * (FX / 2 + 2) * cols);
+    partial.alloc((size_t)slices * (FX + 8) * cols);
     syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices);
     const unsigned tiles = cdiv(cols, 16);
     DevBuf<uint32_t> tl;

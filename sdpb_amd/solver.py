@@ -92,6 +92,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_set_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     L.sdpb_hip_block_owner.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sdpb_hip_limbs.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_fx_frac_bits.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_set_collectives.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Collectives)]
     L.sdpb_hip_timers.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, size_p]
     L.sdpb_hip_plan_blocks.argtypes = [ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int, c_int_p]
@@ -211,6 +212,11 @@ class SDPSolver:
     def limbs(self) -> int:
         return self.L.sdpb_hip_limbs(self.h)
 
+    @property
+    def fx_frac_bits(self) -> int:
+        """Fraction bits of the fixed-point image the exact integer Q syrk works on."""
+        return self.L.sdpb_hip_fx_frac_bits(self.h)
+
     def iterate(self) -> bool:
         """One pass of the loop body of SDP_Solver::run; True when the loop ends."""
         t = ctypes.c_int(0)
@@ -218,6 +224,12 @@ class SDPSolver:
         self.iteration += 1
         self.terminated = bool(t.value)
         return self.terminated
+
+    def reset(self):
+        """Back to the initial point X = Omega_p I, Y = Omega_d I, x = y = 0 (SDP_Solver.cxx:23-38)."""
+        self._chk(self.L.sdpb_hip_init_state(self.h))
+        self.iteration = 0
+        self.terminated = False
 
     def scalar(self, name: str) -> str:
         return self._string(self.L.sdpb_hip_get_scalar, name.encode())

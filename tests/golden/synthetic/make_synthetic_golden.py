@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Generate tests/golden/synthetic/<cfg>.json: per-iteration scalars of the parity oracle
+(oracle/sdpb_oracle.cpp, GMP mpf, pinned against the reference's golden traces) on the
+FULL-SIZE synthetic configurations of BASELINE.json (SURVEY.md §8d generator contract).
+
+The full C4 (J=600, N=1000, P_tot=40000, --precision 512) is the exact workload bench.py
+times; its oracle iteration costs minutes of CPU on all cores, too slow for the GPU box's
+test run, so the expected scalars are produced once here (build container) and committed as
+data.  tests/test_gpu_parity.py::test_gpu_matches_oracle_fixture_at_full_size replays them.
+
+    python tests/golden/synthetic/make_synthetic_golden.py C4 2
+    python tests/golden/synthetic/make_synthetic_golden.py C3 4
+"""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    cfg = sys.argv[1]
+    iters = int(sys.argv[2])
+    scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+    from oracle.oracle import Oracle
+    from sdpb_amd import synthetic
+    from tests import parity
+    c = synthetic.config(cfg, scale)
+    sdp, src = synthetic.make_lazy(c["dims"], c["num_points"], c["N"], c["precision"], c["seed"])
+    t0 = time.time()
+    o = Oracle(sdp, c["precision"], parity.DEFAULT_PARAMS, param_prec=0, block_source=src)
+    print(f"{cfg}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total} p={c['precision']} threads={o.threads} "
+          f"setup {time.time() - t0:.0f}s", flush=True)
+    recs, secs = [], []
+    for it in range(iters):
+        t = time.time()
+        assert not o.iterate(), o.terminate_reason
+        secs.append(time.time() - t)
+        rec = o.scalars()
+        rec["iteration"] = it + 1
+        recs.append(rec)
+        print(f"iteration {it + 1}: {secs[-1]:.0f}s  P-obj={rec['P-obj'][:30]}", flush=True)
+    name = cfg if scale == 1.0 else f"{cfg}_x{scale}"
+    out = {"config": cfg, "scale": scale, "J": sdp.J, "N": sdp.N, "P_tot": sdp.P_total,
+           "precision": c["precision"], "seed": c["seed"], "params": parity.DEFAULT_PARAMS,
+           "generator": "tests/golden/synthetic/make_synthetic_golden.py (oracle/sdpb_oracle.cpp)",
+           "oracle_threads": o.threads, "oracle_seconds_per_iteration": [round(s, 1) for s in secs],
+           "iterations": recs}
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,206 @@
+"""Parity of the gfx950 library at the sizes bench.py runs (through the C ABI).
+
+The golden traces of the reference all have N <= 20 < PB = 32, so they never leave panel 0
+of the look-ahead Cholesky(Q), run one panel of the Q solves and one 16x16 tile row of the
+fixed-point syrk.  The cases here have N > 32, hundreds of blocks, row-split syrk launches
+and all three streams busy — compared with the live oracle (all host cores), with the
+committed full-size oracle fixtures (tests/golden/synthetic/*.json, the exact workload of
+bench.py), array by array on one mixed m=1/m=2 case, and with themselves across repeated
+runs (bit-identical: a stream race would show up as a run-to-run difference).
+Run on the GPU box: python -m pytest tests -m gpu."""
+import json
+import os
+
+import mpmath
+import pytest
+
+from sdpb_amd.solver import SDPSolver
+from tests import libs, parity
+
+pytestmark = pytest.mark.gpu
+SYN = os.path.join(parity.GOLDEN, "synthetic")
+
+
+def _shape(cfg, scale=1.0, **over):
+    from sdpb_amd.synthetic import config
+    c = config(cfg, scale)
+    c.update(over)
+    return c
+
+
+def _pair(c, oracle=True):
+    from oracle.oracle import Oracle
+    from sdpb_amd.synthetic import make_lazy
+    sdp, src = make_lazy(c["dims"], c["num_points"], c["N"], c["precision"], c["seed"])
+    s = SDPSolver(sdp, c["precision"], parity.DEFAULT_PARAMS, lib_path=libs.product_lib(), block_source=src)
+    o = Oracle(sdp, c["precision"], parity.DEFAULT_PARAMS, param_prec=0, block_source=src) if oracle else None
+    return sdp, s, o
+
+
+# C5-shaped (m=6, K=2, --precision 1024) with N > PB: 1024-bit kernels incl. the FX=32 syrk variant
+C5_SLICE = dict(dims=[6] * 24, num_points=[2] * 24, N=72, precision=1024, seed=5)
+
+LIVE = [("C3 full size", _shape("C3"), 3),                      # J=600, N=100: 4 Q panels, 28 syrk tiles x 16 splits
+        ("C4 x0.25", _shape("C4", 0.25), 3),                    # J=150, N=250: 8 Q panels, m=2 blocks with 4 panels
+        ("C5 slice", C5_SLICE, 3)]
+
+
+@pytest.mark.parametrize("name,c,iters", LIVE, ids=[x[0] for x in LIVE])
+def test_gpu_matches_live_oracle_beyond_one_panel(name, c, iters):
+    assert c["N"] > 32
+    sdp, s, o = _pair(c)
+    p = c["precision"]
+    worst = float("-inf")
+    for it in range(iters):
+        ts, to = s.iterate(), o.iterate()
+        assert ts == to, (s.terminate_reason, o.terminate_reason)
+        bad, w = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=p // 2)
+        worst = max(worst, w)
+        assert not bad, f"{name} iteration {it + 1}: {bad}"
+    print(f"{name}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total} p={p}: {iters} iterations, worst log2 rel diff {worst:.1f} "
+          f"(oracle on {o.threads} threads)")
+    s.close()
+    o.close()
+
+
+FIXTURES = sorted(f for f in (os.listdir(SYN) if os.path.isdir(SYN) else []) if f.endswith(".json"))
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_gpu_matches_oracle_fixture_at_full_size(fixture):
+    """The exact workload bench.py times (full C4) against scalars the oracle produced in the build
+    container (tests/golden/synthetic/make_synthetic_golden.py): the parity gate of the metric."""
+    with open(os.path.join(SYN, fixture)) as f:
+        fx = json.load(f)
+    c = _shape(fx["config"], fx["scale"])
+    assert c["seed"] == fx["seed"] and c["N"] == fx["N"] and len(c["dims"]) == fx["J"]
+    sdp, s, _ = _pair(c, oracle=False)
+    p = c["precision"]
+    worst = float("-inf")
+    for rec in fx["iterations"]:
+        assert not s.iterate(), s.terminate_reason
+        bad, w = parity.compare_iteration(s.scalars(), rec, tol_bits=p // 2)
+        worst = max(worst, w)
+        assert not bad, f"{fixture} iteration {rec['iteration']}: {bad}"
+    print(f"{fixture}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total}: {len(fx['iterations'])} iterations, "
+          f"worst log2 rel diff {worst:.1f}")
+    s.close()
+
+
+def test_repeated_runs_are_bit_identical():
+    """Five runs of the same 3 iterations in one process (C4 x0.25: look-ahead Cholesky(Q) on two
+    streams, X/Y chains and step lengths on concurrent streams, row-split syrk) must agree to
+    the last bit: every reduction has a fixed order, so any difference is an ordering bug."""
+    c = _shape("C4", 0.25)
+    sdp, s, _ = _pair(c, oracle=False)
+    runs = []
+    for rep in range(5):
+        s.reset()
+        trace = []
+        for _ in range(3):
+            assert not s.iterate()
+            trace.append(s.scalars())
+        trace.append(s.array("dy")[:50])
+        runs.append(trace)
+    for rep in range(1, 5):
+        assert runs[rep] == runs[0], f"run {rep} differs from run 0"
+    s.close()
+
+
+def _maxrel(got, want):
+    g = [mpmath.mpf(v) for v in got]
+    w = [mpmath.mpf(v) for v in want]
+    assert len(g) == len(w)
+    scale = max(abs(v) for v in w)
+    if scale == 0:
+        return float("-inf") if all(v == 0 for v in g) else 0.0
+    d = max(abs(a - b) for a, b in zip(g, w)) / scale
+    return float(mpmath.log(d, 2)) if d > 0 else float("-inf")
+
+
+def test_intermediate_arrays_match_the_oracle():
+    """Localises a failure to a SURVEY §8a row: the arrays each stage leaves behind after two
+    iterations of C4 x0.05 (m=1 and m=2 blocks, N=50 > PB, Schur blocks of 4 panels) against the
+    oracle's, relative to the largest entry of the array, tolerance 2^-(p/2)."""
+    c = _shape("C4", 0.05)
+    sdp, s, o = _pair(c)
+    p = c["precision"]
+    for _ in range(2):
+        assert not s.iterate() and not o.iterate()
+    N = sdp.N
+    tol = -(p // 2)
+    report = {}
+    steps = (mpmath.mpf(s.scalar("P-step")), mpmath.mpf(s.scalar("D-step")))
+
+    def lower(v, n):  # column-major n x n -> lower triangle entries
+        return [v[i + j * n] for j in range(n) for i in range(j, n)]
+
+    def upper_as_lower(v, n):  # U (column-major) read as L = U^T
+        return [v[j + i * n] for j in range(n) for i in range(j, n)]
+
+    blocks = [0, sdp.J // 2, sdp.J - 1]      # an m=2 block, the middle, an m=1 block
+    assert {sdp.dims[j] for j in blocks} == {1, 2}
+    for j in blocks:
+        P = sdp.num_points[j] * sdp.dims[j] * (sdp.dims[j] + 1) // 2
+        for b in (0, 1):
+            for w in ("X", "Y", "AXinv", "AY", "primal_residues"):                   # a2, a3, a13, a14
+                report[(w, j, b)] = _maxrel(s.array(w, j, b), o.array(w, j, b))
+            # the reference scales dX, dY by the step lengths in place (step.cxx:214-216) and so does
+            # the oracle; the device keeps the search direction itself                   # a10, a12
+            for w, step in (("dX", steps[0]), ("dY", steps[1])):
+                report[(w, j, b)] = _maxrel([mpmath.mpf(v) * step for v in s.array(w, j, b)], o.array(w, j, b))
+            n = len(s.array("Xc", j, b))
+            n = int(round(n ** 0.5))
+            report[("Xc", j, b)] = _maxrel(lower(s.array("Xc", j, b), n), lower(o.array("Xc", j, b), n))  # a1
+            report[("Yc", j, b)] = _maxrel(lower(s.array("Yc", j, b), n), lower(o.array("Yc", j, b), n))
+        report[("L_S", j)] = _maxrel(lower(s.array("L", j), P), lower(o.array("L", j), P))                # a4 + a5
+        pt = s.array("PT", j)                                      # N x P column-major
+        po = o.array("P", j)                                       # P x N column-major
+        report[("P", j)] = _maxrel([pt[n + q * N] for n in range(N) for q in range(P)], po)               # a5
+        for w in ("x", "dx", "dual_residues"):                                                           # a10, a14
+            report[(w, j)] = _maxrel(s.array(w, j), o.array(w, j))
+    report[("chol(Q)",)] = _maxrel(lower(s.array("Q"), N), upper_as_lower(o.array("Q"), N))               # a6-a8
+    for w in ("y", "dy", "primal_residue_p"):
+        report[(w,)] = _maxrel(s.array(w), o.array(w))
+    bad = {k: v for k, v in report.items() if v > tol}
+    print("worst arrays:", sorted(report.items(), key=lambda kv: -kv[1])[:5])
+    assert not bad, bad
+    s.close()
+    o.close()
+
+
+def test_cholesky_Q_failure_is_reported_like_the_reference():
+    """A free variable that appears in no constraint gives Q a zero row: both the oracle and the
+    device path must stop with the reference's message (initialize_schur_complement_solver.cxx:95-103)."""
+    from oracle.oracle import Oracle, OracleError
+    from sdpb_amd.solver import SDPBError
+    from sdpb_amd.synthetic import config, make_sdp
+    c = config("C2")
+    sdp = make_sdp(c["dims"], c["num_points"], c["N"], c["precision"], c["seed"])
+    for blk in sdp.blocks:
+        for row in blk.B:
+            row[3] = "0"
+    o = Oracle(sdp, c["precision"], parity.DEFAULT_PARAMS, param_prec=0)
+    with pytest.raises(OracleError) as eo:
+        o.iterate()
+    s = SDPSolver(sdp, c["precision"], parity.DEFAULT_PARAMS, lib_path=libs.product_lib())
+    with pytest.raises(SDPBError) as es:
+        s.iterate()
+    assert es.value.code == 1
+    assert "Error when computing Cholesky(Q)" in str(eo.value)
+    assert "Error when computing Cholesky(Q)" in str(es.value)
+    s.close()
+    o.close()
+
+
+def test_Y_cholesky_failure_names_block_and_parity():
+    from sdpb_amd.solver import SDPBError
+    sdp, meta, _, _ = parity.load_case("1d-constraints")
+    s = SDPSolver(sdp, meta["precision"], lib_path=libs.product_lib())
+    n = len(s.array("Y", 1, 1))
+    s.set_array("Y", ["-1"] + ["0"] * (n - 1), 1, 1)
+    with pytest.raises(SDPBError) as e:
+        s.iterate()
+    assert e.value.code == 1
+    assert "Block_Diagonal_Matrix Y, block index = 1, parity = 1" in str(e.value)
+    s.close()
