@@ -107,6 +107,11 @@ int sdpb_hip_limbs(sdpb_hip_ctx *ctx);
  * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here 32 (limbs-2) - 7, or - 3 for the
  * limb counts that use one Karatsuba level): inputs of sdpb_hip_op_int_syrk obey |v| < 2^FB. */
 int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx);
+/* Measurement aid (bench/profiling only, never on the solve path): average HIP-event time in
+ * ms of `reps` launches of one kernel of the iteration on synthetic device-resident operands.
+ * op = "syrk": the exact integer Q' = P'^T P' (k_syrk_fx / k_syrk_fx2 + k_syrk_reduce) for a
+ * `a` x `b` fixed-point image of pseudo-random pieces. */
+int sdpb_hip_bench_op(sdpb_hip_ctx *ctx, const char *op, int a, int b, int reps, double *ms);
 
 /* Cross-GPU exchange (world_size > 1), replacing the El::mpi collectives listed in
  * SURVEY.md §2a.  The library hands DEVICE pointers it owns to these callbacks:

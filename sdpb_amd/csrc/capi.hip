@@ -194,6 +194,14 @@ int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j)
 }
 int sdpb_hip_limbs(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->limbs() : 0; }
 int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->fx_frac_bits() : 0; }
+int sdpb_hip_bench_op(sdpb_hip_ctx *ctx, const char *op, int a, int b, int reps, double *ms)
+{
+  return guarded(ctx, [&] {
+    if(!op || !ms)
+      throw sdpb::SolverError(4, "sdpb_hip_bench_op: null argument");
+    *ms = ctx->solver->bench_op(op, a, b, reps);
+  });
+}
 
 int sdpb_hip_set_collectives(sdpb_hip_ctx *ctx, const sdpb_hip_collectives *c)
 {

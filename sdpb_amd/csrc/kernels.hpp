@@ -1725,6 +1725,78 @@ __global__ void __launch_bounds__(WG) k_fx_colsum2_final(const uint32_t *partial
     acc[(size_t)k * acc_stride + (size_t)N * N + col] = w[k];
 }
 
+// one M2-limb piece with the widest loads its size allows (pieces are M2*4-byte aligned)
+struct alignas(16) PieceQuad
+{
+  uint32_t w[4];
+};
+struct alignas(8) PiecePair
+{
+  uint32_t w[2];
+};
+template <int M2> MW_HD void piece_load(const uint32_t *p, uint32_t (&x)[M2])
+{
+  if constexpr(M2 % 4 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 4; ++q)
+        {
+          const PieceQuad v = *reinterpret_cast<const PieceQuad *>(p + 4 * q);
+#pragma unroll
+          for(int l = 0; l < 4; ++l)
+            x[4 * q + l] = v.w[l];
+        }
+    }
+  else if constexpr(M2 % 2 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 2; ++q)
+        {
+          const PiecePair v = *reinterpret_cast<const PiecePair *>(p + 2 * q);
+          x[2 * q] = v.w[0];
+          x[2 * q + 1] = v.w[1];
+        }
+    }
+  else
+    {
+#pragma unroll
+      for(int l = 0; l < M2; ++l)
+        x[l] = p[l];
+    }
+}
+template <int M2> MW_HD void piece_store(uint32_t *p, const uint32_t (&x)[M2])
+{
+  if constexpr(M2 % 4 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 4; ++q)
+        {
+          PieceQuad v;
+#pragma unroll
+          for(int l = 0; l < 4; ++l)
+            v.w[l] = x[4 * q + l];
+          *reinterpret_cast<PieceQuad *>(p + 4 * q) = v;
+        }
+    }
+  else if constexpr(M2 % 2 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 2; ++q)
+        {
+          PiecePair v;
+          v.w[0] = x[2 * q];
+          v.w[1] = x[2 * q + 1];
+          *reinterpret_cast<PiecePair *>(p + 2 * q) = v;
+        }
+    }
+  else
+    {
+#pragma unroll
+      for(int l = 0; l < M2; ++l)
+        p[l] = x[l];
+    }
+}
+
 // d -= x (both A limbs, d >= x)
 template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
 {
@@ -1747,6 +1819,12 @@ template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
 // (2 M2 + 2)-limb sum once.  The pieces of the NEXT pass are fetched from HBM/L2 into registers
 // while the MACs run and are written to the other LDS buffer when the pass ends (one barrier
 // per pass).  The nine sums are recombined once per output element after the row loop.
+#ifndef SDPB_SYRK2_UNROLL
+#define SDPB_SYRK2_UNROLL 2 // rows whose LDS reads are in flight together (registers: 2 M2 per row)
+#endif
+#ifndef SDPB_SYRK2_PREFETCH
+#define SDPB_SYRK2_PREFETCH 1
+#endif
 template <int FX, int RBG>
 __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   k_syrk_fx2(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
@@ -1788,13 +1866,14 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
         const bool ok = r < row_end;
         // lanes outside the image read a valid piece and drop it: no divergent branches
         const uint32_t *row = fx + ((size_t)g * fx_stride + (size_t)(ok ? r : row_begin) * (size_t)N) * M2;
-        const uint32_t *pa = row + (size_t)(ca < N ? ca : 0) * M2, *pb = row + (size_t)(cb < N ? cb : 0) * M2;
+        piece_load<M2>(row + (size_t)(ca < N ? ca : 0) * M2, va[t]);
+        piece_load<M2>(row + (size_t)(cb < N ? cb : 0) * M2, vb[t]);
+        const uint32_t ma = (ok && ca < N) ? 0xffffffffu : 0u, mb = (ok && cb < N) ? 0xffffffffu : 0u;
 #pragma unroll
         for(int l = 0; l < M2; ++l)
           {
-            const uint32_t xa = pa[l], xb = pb[l];
-            va[t][l] = (ok && ca < N) ? xa : 0u; // rows past the end and columns past N: zero limbs,
-            vb[t][l] = (ok && cb < N) ? xb : 0u; // they add nothing to any product
+            va[t][l] &= ma; // rows past the end and columns past N: zero limbs,
+            vb[t][l] &= mb; // they add nothing to any product
           }
       }
   };
@@ -1803,12 +1882,8 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
     for(int t = 0; t < GL; ++t)
       {
         const int e = threadIdx.x + t * WG;
-#pragma unroll
-        for(int l = 0; l < M2; ++l)
-          {
-            sa[(buf * NP + e) * M2 + l] = va[t][l];
-            sb[(buf * NP + e) * M2 + l] = vb[t][l];
-          }
+        piece_store<M2>(sa + (buf * NP + e) * M2, va[t]);
+        piece_store<M2>(sb + (buf * NP + e) * M2, vb[t]);
       }
   };
   fetch(0, row_begin);
@@ -1830,18 +1905,32 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
               h[k] = 0;
             }
           const uint32_t *pa = sa + (buf * NP + li) * M2, *pb = sb + (buf * NP + lj) * M2;
-#pragma unroll 4
+#if SDPB_SYRK2_PREFETCH
+          // the LDS reads of the next row are issued before the MACs of the current one
+          uint32_t a0[M2], b0[M2], a1[M2], b1[M2];
+          piece_load<M2>(pa, a0);
+          piece_load<M2>(pb, b0);
+#pragma unroll 1
+          for(int rr = 0; rr < RBG; rr += 2)
+            {
+              piece_load<M2>(pa + (rr + 1) * 16 * M2, a1);
+              piece_load<M2>(pb + (rr + 1) * 16 * M2, b1);
+              SyrkColumns<M2, 0>::run(a0, b0, c, h);
+              const int nx = rr + 2 < RBG ? rr + 2 : 0; // the read past the last row is dropped
+              piece_load<M2>(pa + nx * 16 * M2, a0);
+              piece_load<M2>(pb + nx * 16 * M2, b0);
+              SyrkColumns<M2, 0>::run(a1, b1, c, h);
+            }
+#else
+#pragma unroll SDPB_SYRK2_UNROLL
           for(int rr = 0; rr < RBG; ++rr)
             {
               uint32_t a[M2], b[M2];
-#pragma unroll
-              for(int l = 0; l < M2; ++l)
-                {
-                  a[l] = pa[rr * 16 * M2 + l];
-                  b[l] = pb[rr * 16 * M2 + l];
-                }
+              piece_load<M2>(pa + rr * 16 * M2, a);
+              piece_load<M2>(pb + rr * 16 * M2, b);
               SyrkColumns<M2, 0>::run(a, b, c, h);
             }
+#endif
           syrk_fold<M2>(g2[g], c, h);
           store(buf ^ 1);
           __syncthreads();

@@ -119,6 +119,7 @@ public:
   virtual std::string timers_json() const = 0;
   virtual int limbs() const = 0;
   virtual int fx_frac_bits() const = 0;
+  virtual double bench_op(const std::string &op, int a, int b, int reps) = 0;
   // operator-level entry points for parity tests
   virtual std::string op_scalar(const std::string &op, const char *a, const char *b) = 0;
   virtual std::string op_int_syrk(int rows, int cols, const char *ints_colmajor) = 0;
@@ -1605,6 +1606,44 @@ public:
     });
     HIP_CHECK(hipStreamSynchronize(stream_));
     return mw::to_decimal<NL>(download<NL>(io, 2, 1)[0]);
+  }
+
+  // sdpb_hip_bench_op: average HIP-event time of one kernel on synthetic operands (ms)
+  double bench_op(const std::string &op, int a, int b, int reps) override
+  {
+    if(op != "syrk" || a <= 0 || b <= 0)
+      throw SolverError(4, "bench_op: unknown op " + op);
+    const int rows = a, cols = b;
+    const size_t cnt = (size_t)rows * cols;
+    DevBuf<uint32_t> fx, acc, part, tl;
+    fx.alloc(cnt * fx_planes<FX>());
+    {
+      // pseudo-random limbs with the top bit of every word clear (valid pieces of both image layouts)
+      uint32_t *p = fx.p;
+      foreach(cnt * fx_planes<FX>(), [=] __device__(size_t i) {
+        uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        p[i] = (uint32_t)(z >> 33);
+      });
+    }
+    const size_t as = (size_t)cols * cols + cols;
+    acc.alloc(as * ACCW);
+    tl.upload(syrk_tile_order(cols));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part); // warm-up (sizes `part`)
+    HIP_CHECK(hipEventRecord(e0, stream_));
+    for(int r = 0; r < std::max(reps, 1); ++r)
+      syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part);
+    HIP_CHECK(hipEventRecord(e1, stream_));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ms / std::max(reps, 1);
   }
 
   // Exact integer syrk of a rows x cols integer matrix (column-major decimal

@@ -93,6 +93,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_block_owner.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sdpb_hip_limbs.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_fx_frac_bits.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_bench_op.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_double)]
     L.sdpb_hip_set_collectives.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Collectives)]
     L.sdpb_hip_timers.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, size_p]
     L.sdpb_hip_plan_blocks.argtypes = [ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int, c_int_p]
@@ -277,6 +279,12 @@ class SDPSolver:
     def op_int_syrk(self, rows: int, cols: int, ints_colmajor) -> List[int]:
         txt = " ".join(str(v) for v in ints_colmajor).encode()
         return [int(s) for s in self._string(self.L.sdpb_hip_op_int_syrk, rows, cols, txt).split()]
+
+    def bench_op(self, op: str, a: int, b: int, reps: int = 3) -> float:
+        """Average HIP-event time (ms) of one kernel of the iteration on synthetic operands."""
+        ms = ctypes.c_double(0.0)
+        self._chk(self.L.sdpb_hip_bench_op(self.h, op.encode(), a, b, reps, ctypes.byref(ms)))
+        return ms.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -26,25 +26,30 @@ def test_emulated_library_matches_reference_golden(name, limit):
     s.close()
 
 
-@pytest.mark.parametrize("splits", [None, "3"])
-def test_emulated_int_syrk_is_exact(splits, monkeypatch):
+@pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (128, 70, 21, "3"), (512, 45, 18, None),
+                                                        (664, 20, 17, None)])
+def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     import random
     if splits:
         monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", splits)  # row-split partial sums + k_syrk_reduce
     from oracle.oracle import Oracle
     sdp, meta, _, _ = parity.load_case("1d")
-    s = SDPSolver(sdp, 128, lib_path=libs.emu_lib())  # NL=6 -> FX=4: |v| < 2^(32 FX - 3) = 2^125
-    o = Oracle(sdp, 128)
+    s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
+    o = Oracle(sdp, precision)
+    fb = s.fx_frac_bits           # 32 FX - 7 with two Karatsuba levels (FX % 4 == 0), else 32 FX - 3
+    fx = s.limbs - 2
+    assert fb == 32 * fx - (7 if fx % 4 == 0 and fx <= 24 else 3)
     rng = random.Random(7)
-    rows, cols = 37, 21
-    vals = [rng.randrange(-(2 ** 125) + 1, 2 ** 125) for _ in range(rows * cols)]
+    vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
     vals[5] = 0
-    vals[11] = 2 ** 125 - 1
-    vals[12] = -(2 ** 125) + 1
+    vals[11] = 2 ** fb - 1
+    vals[12] = -(2 ** fb) + 1
     vals[13] = 1
     vals[14] = -1
-    vals[15] = 2 ** 63            # exactly the Karatsuba split point 2^(32 M - 1)
-    vals[16] = -(2 ** 63) + 1
+    # exactly at / next to the split points of the image a' = v + 2^fb (first and second level)
+    for k, bit in enumerate((16 * fx - 1, 16 * fx - 3, 8 * fx - 1, 24 * fx - 4)):
+        vals[15 + 2 * k] = 2 ** bit - 2 ** fb if bit < fb else 2 ** (bit - 1)
+        vals[16 + 2 * k] = 2 ** bit - 2 ** fb - 1 if bit < fb else -(2 ** (bit - 1))
     got = s.op_int_syrk(rows, cols, vals)
     want = o.int_syrk(rows, cols, vals)  # upper triangle, column-major
     for j in range(cols):
