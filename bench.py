@@ -177,8 +177,23 @@ def main():
     solver = SDPSolver(sdp, precision, device=local_rank, rank=rank, world_size=sim or world, upload_all_blocks=False,
                        block_source=source)
     if world > 1:
-        from sdpb_amd.distributed import make_collectives
-        solver.set_collectives(*make_collectives(device))
+        # the exchange runs on RCCL inside the library (its own stream, no host synchronisation);
+        # torch.distributed only carries the 128-byte id and the timing barrier
+        comm = None
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(solver.rccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            solver.rccl_init(bytes(uid.cpu().numpy().tobytes()))
+            comm = solver.comm_name
+        except Exception as e:  # keep the run alive on the callback path (torch.distributed = RCCL as well)
+            print(f"[bench rank {rank}] in-library RCCL init failed ({e}); using torch.distributed callbacks", flush=True)
+        ok = torch.tensor([1 if comm == "rccl" else 0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            from sdpb_amd.distributed import make_collectives
+            solver.set_collectives(*make_collectives(device))
     elif sim:
         from sdpb_amd.distributed import tensor_from_pointer
 
@@ -205,6 +220,7 @@ def main():
     for _ in range(args.warmup):
         assert not solver.iterate(), solver.terminate_reason
     timers0 = solver.timers()
+    syncs0 = solver.host_syncs
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -218,6 +234,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timers1 = solver.timers()
+    syncs1 = solver.host_syncs
+    # per-stage breakdown: one extra, UNTIMED iteration with the stage timers on (they synchronise
+    # the stream at every stage boundary, so they are off inside the timed region)
+    solver.set_profiling(True)
+    tp0 = solver.timers()
+    assert not solver.iterate(), solver.terminate_reason
+    tp1 = solver.timers()
+    solver.set_profiling(False)
 
     if rank == 0:
         ms_per_step = 1000.0 * dt / args.steps
@@ -230,12 +254,12 @@ def main():
         k_macs = timers1["kernel.k_syrk_fx.limb_macs"]
         achieved = k_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_k_syrk_fx.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_k_syrk_fx.json")
         if os.path.exists(pmc) and args.workload == "C4" and args.scale == 1.0 and world == 1:
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
-        stages = {k: round((timers1[k] - timers0.get(k, 0.0)) / args.steps, 3) for k in timers1
-                  if not k.startswith("kernel.")}
+        skip = ("kernel.", "host_syncs", "iterations")
+        stages = {k: round(tp1[k] - tp0.get(k, 0.0), 3) for k in tp1 if not k.startswith(skip)}
         nl = solver.limbs
         from sdpb_amd.solver import copy_bandwidth_gbs
         copy_gbs = copy_bandwidth_gbs(1 << 30, 5)
@@ -248,7 +272,9 @@ def main():
             "config": {"workload": f"{args.workload}: synthetic 3d-Ising mixed-correlator SDP (SURVEY.md §8d), "
                                    f"J={sdp.J}, N={sdp.N}, P_tot={sdp.P_total}, --precision {precision}"
                                    + ("" if args.scale == 1.0 else f" [scaled x{args.scale}]"),
-                       "parallelism": f"blocks sharded over {world} GPU(s); Q' summed by integer all-reduce"},
+                       "parallelism": f"blocks sharded over {world} GPU(s); Q' summed by integer all-reduce",
+                       "exchange": solver.comm_name},
+            "host_syncs_per_step": (syncs1 - syncs0) / args.steps,
             "roofline": {"bound": "hbm", "kernel": "k_syrk_fx", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_copy_peak": copy_gbs,
@@ -257,7 +283,7 @@ def main():
                          "limb_mac_frac_of_measured_valu_peak": (k_macs / k_avg_s / LIMB_MAC_PEAK) if k_avg_s > 0 else 0.0},
             "algorithmic_bytes_per_iteration": workmodel.algorithmic_bytes_per_iteration(
                 cfg["dims"], cfg["num_points"], cfg["N"], 4 * (nl + 1)),
-            "stage_ms_per_step": stages,
+            "stage_ms_profiled_iteration": stages,
             "setup_s": t_setup,
         }
         if sim:

@@ -98,6 +98,27 @@ int sdpb_hip_get_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, 
 /* Inject x, X, y or Y (text checkpoint: load_text_checkpoint.cxx:6-44). */
 int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, const char *values);
 
+/* ---- binary number path -------------------------------------------------------
+ * The same entry points with every number as a fixed-width record in GMP's mpf_t layout, so
+ * a C++ caller holding El::BigFloat (= mpf_t, fmpz_BigFloat_convert.hxx:9,13) never formats
+ * decimals: one record = 2 + limbs64 64-bit words,
+ *   word 0 = (int64) _mp_size (signed count of used limbs; 0 = zero),
+ *   word 1 = (int64) _mp_exp  (exponent in 64-bit limbs),
+ *   words 2.. = _mp_d[0 .. limbs64), least significant limb first (unused limbs ignored),
+ *   value = sign * (sum_i d[i] 2^(64 i)) * 2^(64 (_mp_exp - |_mp_size|)).
+ * Conversions truncate toward zero like mpf; reading back is exact when
+ * limbs64 >= sdpb_hip_limbs(ctx)/2 + 1 (GMP's own _mp_prec + 1 at the same --precision).
+ * Shapes and orders are those of the text entry points (B row-major P x N, arrays column-major). */
+int sdpb_hip_set_block_mpf(sdpb_hip_ctx *ctx, int j, int limbs64, const unsigned long long *bilinear_bases_even,
+                           const unsigned long long *bilinear_bases_odd, const unsigned long long *B,
+                           const unsigned long long *c);
+int sdpb_hip_set_objective_mpf(sdpb_hip_ctx *ctx, int limbs64, const unsigned long long *b, const unsigned long long *constant);
+/* *count receives the number of elements; nothing is written when capacity < *count. */
+int sdpb_hip_get_array_mpf(sdpb_hip_ctx *ctx, const char *which, int j, int parity, int limbs64, unsigned long long *out,
+                           size_t capacity, size_t *count);
+int sdpb_hip_set_array_mpf(sdpb_hip_ctx *ctx, const char *which, int j, int parity, int limbs64,
+                           const unsigned long long *values, size_t count);
+
 /* Rank that owns block j (block_info.block_indices in the reference). */
 int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j);
 /* 32-bit limbs of the device mantissa chosen for precision_bits. */
@@ -127,6 +148,39 @@ typedef struct
   void *user;
 } sdpb_hip_collectives;
 int sdpb_hip_set_collectives(sdpb_hip_ctx *ctx, const sdpb_hip_collectives *c);
+
+/* The same exchange on RCCL over xGMI inside the library (one process per GPU): the
+ * collectives are enqueued on the library's own stream, with no host synchronisation.
+ * Rank 0 obtains an id, the host program hands those bytes to every rank (MPI_Bcast, a
+ * file, torch.distributed, ...), then EVERY rank of the context's world calls
+ * sdpb_hip_rccl_init (collective).  Replaces the El::mpi collectives of SDP_Solver::step
+ * (restore_and_reduce.cxx:137-212, compute_search_direction.cxx:74, step_length.cxx:39,
+ * compute_feasible_and_termination.cxx:66-69).  sdpb_hip_comm_name: "none" (1 rank),
+ * "rccl", "callbacks" or "unset". */
+#define SDPB_HIP_RCCL_ID_BYTES 128
+int sdpb_hip_rccl_unique_id(char id[SDPB_HIP_RCCL_ID_BYTES]);
+int sdpb_hip_rccl_init(sdpb_hip_ctx *ctx, const char id[SDPB_HIP_RCCL_ID_BYTES]);
+const char *sdpb_hip_comm_name(sdpb_hip_ctx *ctx);
+/* Self-test of the RCCL binding on the current device with a one-rank communicator: an
+ * all-gather of `bytes` bytes and a SUM all-reduce of bytes/8 64-bit lanes through the same
+ * code path the solver uses must return the data unchanged.  0 = ok. */
+int sdpb_hip_rccl_selftest(size_t bytes);
+
+/* --maxRuntime (Solver_Parameters.hxx:27): the wall-clock test of
+ * compute_feasible_and_termination.cxx:51-56, taken between MaxIterationsExceeded and
+ * PrimalStepTooSmall; with several ranks every rank follows rank 0's clock (":66-69").
+ * The clock starts at the first sdpb_hip_iterate after sdpb_hip_init_state. */
+int sdpb_hip_set_max_runtime(sdpb_hip_ctx *ctx, double seconds);
+/* Graceful stop (run.cxx:332-355): async-signal-safe, may be called from a SIGTERM handler
+ * on any rank; the next sdpb_hip_iterate of EVERY rank returns terminated with reason
+ * "SIGTERM signal received" and leaves x, X, y, Y untouched for the checkpoint. */
+void sdpb_hip_request_stop(sdpb_hip_ctx *ctx);
+/* Stage timers synchronise the stream at every stage boundary, so they are off unless asked
+ * for (the reference's timers cost only at --verbosity >= 2); also SDPB_HIP_PROFILE=1. */
+int sdpb_hip_set_profiling(sdpb_hip_ctx *ctx, int on);
+/* Host synchronisation points executed so far (3 per iteration: termination test,
+ * corrector centering parameter, step lengths). */
+long sdpb_hip_host_syncs(sdpb_hip_ctx *ctx);
 
 /* Accumulated wall time per stage in ms as a JSON object; names follow the reference's
  * Scoped_Timer hierarchy below "run.iter_*." (SURVEY.md §5). */

@@ -57,6 +57,9 @@ def lib():
         L.orc_parse_exact.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.orc_scalar_op.restype = ctypes.c_char_p
         L.orc_scalar_op.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 3
+        L.orc_get_records.restype = ctypes.c_long
+        L.orc_get_records.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_long]
         L.orc_set_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
         _lib = L
@@ -130,6 +133,17 @@ class Oracle:
 
     def array(self, which: str, j: int = 0, parity: int = 0):
         return self.L.orc_get_array(self.h, which.encode(), j, parity).decode().split()
+
+    def records(self, which: str, j: int = 0, parity: int = 0, limbs64: int = 10):
+        """The oracle's own mpf_t values as raw records (_mp_size, _mp_exp, _mp_d[0..limbs64)):
+        numpy uint64 array of shape (count, 2 + limbs64)."""
+        import numpy as np
+        n = self.L.orc_get_records(self.h, which.encode(), j, parity, limbs64, None, 0)
+        if n < 0:
+            raise OracleError(f"unknown array {which}")
+        out = np.zeros((n, 2 + limbs64), dtype=np.uint64)
+        self.L.orc_get_records(self.h, which.encode(), j, parity, limbs64, out.ctypes.data_as(ctypes.c_void_p), n)
+        return out
 
     @property
     def terminate_reason(self) -> str:

@@ -1753,6 +1753,62 @@ const char *orc_get_array(void *h, const char *which, int j, int parity)
   return o->strbuf.c_str();
 }
 
+// ---- raw mpf_t records (tests of the product's binary number path) ----------
+// One number = 2 + limbs64 words copied straight from the mpf_t: _mp_size, _mp_exp, _mp_d
+// (the low limbs are dropped when the mpf_t holds more than limbs64).
+static void put_record(const F &f, uint64_t *rec, int limbs64)
+{
+  const long size = f.v->_mp_size, n = size < 0 ? -size : size, keep = n < limbs64 ? n : limbs64;
+  for(int i = 0; i < limbs64 + 2; ++i)
+    rec[i] = 0;
+  rec[0] = (uint64_t)(long long)(size < 0 ? -keep : keep);
+  rec[1] = (uint64_t)(long long)f.v->_mp_exp;
+  for(long i = 0; i < keep; ++i)
+    rec[2 + i] = f.v->_mp_d[n - keep + i];
+}
+// which: "bases_even", "bases_odd" (row-major rows x K), "B" (row-major P x N), "c", "b", "constant",
+// or any orc_get_array name (column-major).  Returns the element count; writes when capacity allows.
+long orc_get_records(void *h, const char *which, int j, int parity, int limbs64, uint64_t *out, long capacity)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  const std::string w(which);
+  std::vector<const F *> v;
+  auto rowmajor = [&](const Mat &m) {
+    for(int r = 0; r < m.h; ++r)
+      for(int c = 0; c < m.w; ++c)
+        v.push_back(&m(r, c));
+  };
+  auto colmajor = [&](const Mat &m) {
+    for(auto &e : m.a)
+      v.push_back(&e);
+  };
+  auto vec = [&](const std::vector<F> &x) {
+    for(auto &e : x)
+      v.push_back(&e);
+  };
+  if(w == "b") vec(o->b);
+  else if(w == "constant") v.push_back(&o->objective_const);
+  else if(w == "y") vec(o->y);
+  else if(w == "dy") vec(o->dy);
+  else
+    {
+      Block &bl = o->blk.at(j);
+      if(w == "bases_even") rowmajor(bl.bases[0]);
+      else if(w == "bases_odd") rowmajor(bl.bases[1]);
+      else if(w == "B") rowmajor(bl.B);
+      else if(w == "c") vec(bl.c);
+      else if(w == "x") vec(bl.x);
+      else if(w == "dx") vec(bl.dx);
+      else if(w == "X") colmajor(bl.X[parity]);
+      else if(w == "Y") colmajor(bl.Y[parity]);
+      else return -1;
+    }
+  if(out && capacity >= (long)v.size())
+    for(size_t i = 0; i < v.size(); ++i)
+      put_record(*v[i], out + i * (size_t)(limbs64 + 2), limbs64);
+  return (long)v.size();
+}
+
 // ---- kernel-level oracles (calculate_matrix_square.test.cxx recipe) --------
 // Exact integer syrk: inputs are P' as decimal *integers* (rows x cols,
 // column-major), output upper triangle of Q' = P'^T P' as decimal integers

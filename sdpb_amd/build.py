@@ -97,7 +97,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for o in todo:
             _mark(o, digest)
     if jobs or not os.path.exists(LIB):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        # RCCL (the in-library cross-GPU exchange, csrc/rccl_comm.hpp); in a process that has already
+        # loaded PyTorch the dynamic linker binds librccl.so.1 / libamdhip64 to torch's copies
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl"])
     return LIB
 
 

@@ -186,6 +186,36 @@ int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, 
 {
   return guarded(ctx, [&] { ctx->solver->set_array(which, j, parity, values); });
 }
+int sdpb_hip_set_block_mpf(sdpb_hip_ctx *ctx, int j, int limbs64, const unsigned long long *be, const unsigned long long *bo,
+                           const unsigned long long *B, const unsigned long long *c)
+{
+  return guarded(ctx, [&] {
+    ctx->solver->set_block_mpf(j, limbs64, (const uint64_t *)be, (const uint64_t *)bo, (const uint64_t *)B, (const uint64_t *)c);
+  });
+}
+int sdpb_hip_set_objective_mpf(sdpb_hip_ctx *ctx, int limbs64, const unsigned long long *b, const unsigned long long *constant)
+{
+  return guarded(ctx, [&] { ctx->solver->set_objective_mpf(limbs64, (const uint64_t *)b, (const uint64_t *)constant); });
+}
+int sdpb_hip_get_array_mpf(sdpb_hip_ctx *ctx, const char *which, int j, int parity, int limbs64, unsigned long long *out,
+                           size_t capacity, size_t *count)
+{
+  return guarded(ctx, [&] {
+    if(!which || !count)
+      throw sdpb::SolverError(4, "sdpb_hip_get_array_mpf: null argument");
+    *count = ctx->solver->get_array_mpf(which, j, parity, limbs64, (uint64_t *)out, capacity);
+  });
+}
+int sdpb_hip_set_array_mpf(sdpb_hip_ctx *ctx, const char *which, int j, int parity, int limbs64,
+                           const unsigned long long *values, size_t count)
+{
+  return guarded(ctx, [&] {
+    if(!which)
+      throw sdpb::SolverError(4, "sdpb_hip_set_array_mpf: null argument");
+    ctx->solver->set_array_mpf(which, j, parity, limbs64, (const uint64_t *)values, count);
+  });
+}
+
 int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j)
 {
   int r = -1;
@@ -216,6 +246,83 @@ int sdpb_hip_set_collectives(sdpb_hip_ctx *ctx, const sdpb_hip_collectives *c)
     ctx->solver->set_collectives(cc);
   });
 }
+int sdpb_hip_rccl_unique_id(char id[SDPB_HIP_RCCL_ID_BYTES])
+{
+  try
+    {
+      if(!id)
+        return fail(nullptr, 4, "sdpb_hip_rccl_unique_id: null buffer");
+      std::memset(id, 0, SDPB_HIP_RCCL_ID_BYTES);
+      sdpb::rccl_unique_id(id, SDPB_HIP_RCCL_ID_BYTES);
+      return 0;
+    }
+  catch(sdpb::SolverError &e)
+    {
+      return fail(nullptr, e.code, e.what());
+    }
+  catch(std::exception &e)
+    {
+      return fail(nullptr, 3, e.what());
+    }
+}
+int sdpb_hip_rccl_init(sdpb_hip_ctx *ctx, const char id[SDPB_HIP_RCCL_ID_BYTES])
+{
+  return guarded(ctx, [&] {
+    if(!id)
+      throw sdpb::SolverError(4, "sdpb_hip_rccl_init: null id");
+    ctx->solver->init_rccl(id, SDPB_HIP_RCCL_ID_BYTES);
+  });
+}
+const char *sdpb_hip_comm_name(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->comm_name() : ""; }
+int sdpb_hip_rccl_selftest(size_t bytes)
+{
+  try
+    {
+      const size_t n = std::max<size_t>(bytes / 8, 1);
+      char id[SDPB_HIP_RCCL_ID_BYTES];
+      sdpb::rccl_unique_id(id, sizeof id);
+      std::unique_ptr<sdpb::Comm> comm(sdpb::make_rccl_comm(id, sizeof id, 0, 1));
+      std::vector<unsigned long long> h(n), back(n);
+      for(size_t i = 0; i < n; ++i)
+        h[i] = 0x9E3779B97F4A7C15ull * (i + 1);
+      sdpb::DevBuf<unsigned long long> a, b;
+      a.upload(h);
+      b.alloc(n);
+      hipStream_t st;
+      HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      comm->allgather(a.p, b.p, n * 8, st);
+      comm->allreduce_sum_u64(b.p, n, st);
+      HIP_CHECK(hipMemcpyAsync(back.data(), b.p, n * 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      (void)hipStreamDestroy(st);
+      if(back != h)
+        return fail(nullptr, 3, "sdpb_hip_rccl_selftest: data changed in a one-rank all-gather + all-reduce");
+      return 0;
+    }
+  catch(sdpb::SolverError &e)
+    {
+      return fail(nullptr, e.code, e.what());
+    }
+  catch(std::exception &e)
+    {
+      return fail(nullptr, 3, e.what());
+    }
+}
+int sdpb_hip_set_max_runtime(sdpb_hip_ctx *ctx, double seconds)
+{
+  return guarded(ctx, [&] { ctx->solver->set_max_runtime(seconds); });
+}
+void sdpb_hip_request_stop(sdpb_hip_ctx *ctx)
+{
+  if(ctx)
+    ctx->solver->request_stop();
+}
+int sdpb_hip_set_profiling(sdpb_hip_ctx *ctx, int on)
+{
+  return guarded(ctx, [&] { ctx->solver->set_profiling(on != 0); });
+}
+long sdpb_hip_host_syncs(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->host_syncs() : 0; }
+
 int sdpb_hip_timers(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed)
 {
   int rc = guarded(ctx, [&] { ctx->strbuf = ctx->solver->timers_json(); });

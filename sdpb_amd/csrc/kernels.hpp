@@ -2416,6 +2416,203 @@ template <int NL> __global__ void __launch_bounds__(DR_T) k_diag_ratio(Batch L, 
     mw::store<NL>(out, out_off + q, d.rows > 0 ? mw::div(smx[0], smn[0]) : mw::zero<NL>());
 }
 
+// ---- scalars that stay on the device -------------------------------------------
+// A host scalar becomes a kernel argument (no H2D copy, stream ordered).
+template <int NL> __global__ void k_store_scalar(mw::Ptr p, size_t idx, Mw<NL> v)
+{
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    mw::store<NL>(p, idx, v);
+}
+
+template <int UNUSED = 0> __global__ void k_store_words4(uint32_t *p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      p[0] = w0;
+      p[1] = w1;
+      p[2] = w2;
+      p[3] = w3;
+    }
+}
+
+// Result block of one rank: `nslots` numbers (limb-major, stride nslots) followed by
+// X_EXTRA raw words.  The host reads the whole block with ONE copy per synchronisation
+// point; with several ranks the blocks are all-gathered and k_combine_slots applies one
+// operation per slot, in rank order, so every rank ends with identical bits.
+enum XOp : int
+{
+  X_KEEP = 0, // rank-local or replicated: untouched
+  X_SUM,
+  X_MAX,
+  X_MIN,
+  X_ARGMAX // value of the first rank holding the maximum; extra word XW_TAG follows the winner
+};
+constexpr int X_MAXSLOTS = 24;
+constexpr int X_EXTRA = 4;
+enum XWord : int
+{
+  XW_FAIL = 0, // smallest failure tag (0xffffffff = none): every rank raises the same error
+  XW_STOP,     // rank 0's wall-clock / signal decision (compute_feasible_and_termination.cxx broadcasts rank 0's)
+  XW_OR,       // OR of per-rank flags (SIGTERM received anywhere, run.cxx:332-336)
+  XW_TAG       // which matrix holds the largest Cholesky condition number
+};
+struct XOps
+{
+  int op[X_MAXSLOTS];
+};
+template <int NL> __global__ void __launch_bounds__(64) k_combine_slots(const uint32_t *recv, int world, int nslots, XOps ops, uint32_t *local)
+{
+  const size_t blk = (size_t)(NL + 1) * nslots + X_EXTRA, xoff = (size_t)(NL + 1) * nslots;
+  const int s = threadIdx.x;
+  if(s < nslots && ops.op[s] != X_KEEP)
+    {
+      const int op = ops.op[s];
+      Mw<NL> r = mw::load<NL>(mw::CPtr(recv, (size_t)nslots), s);
+      int win = 0;
+      for(int k = 1; k < world; ++k)
+        {
+          const Mw<NL> v = mw::load<NL>(mw::CPtr(recv + (size_t)k * blk, (size_t)nslots), s);
+          if(op == X_SUM)
+            r = mw::add(r, v);
+          else if(op == X_MAX)
+            r = mw::max(r, v);
+          else if(op == X_MIN)
+            r = mw::min(r, v);
+          else if(mw::lt(r, v))
+            {
+              r = v;
+              win = k;
+            }
+        }
+      mw::store<NL>(mw::Ptr{local, (size_t)nslots}, s, r);
+      if(op == X_ARGMAX)
+        local[xoff + XW_TAG] = recv[(size_t)win * blk + xoff + XW_TAG];
+    }
+  if(s == nslots)
+    {
+      uint32_t f = 0xffffffffu, o = 0;
+      for(int k = 0; k < world; ++k)
+        {
+          const uint32_t fk = recv[(size_t)k * blk + xoff + XW_FAIL];
+          f = fk < f ? fk : f;
+          o |= recv[(size_t)k * blk + xoff + XW_OR];
+        }
+      local[xoff + XW_FAIL] = f;
+      local[xoff + XW_STOP] = recv[xoff + XW_STOP];
+      local[xoff + XW_OR] = o;
+    }
+}
+// out[i] = sum over ranks (rank order) of the gathered n-vectors; out has stride n
+template <int NL> __global__ void __launch_bounds__(WG) k_combine_vec(const uint32_t *recv, int world, int n, mw::Ptr out)
+{
+  const int i = blockIdx.x * WG + threadIdx.x;
+  if(i >= n)
+    return;
+  const size_t blk = (size_t)(NL + 1) * n;
+  Mw<NL> r = mw::load<NL>(mw::CPtr(recv, (size_t)n), i);
+  for(int k = 1; k < world; ++k)
+    r = mw::add(r, mw::load<NL>(mw::CPtr(recv + (size_t)k * blk, (size_t)n), i));
+  mw::store<NL>(out, i, r);
+}
+// out = base (+/-) out, element-wise (gemv_t_all after the cross-rank sum)
+template <int NL> __global__ void __launch_bounds__(WG) k_base_plus_signed(mw::Ptr out, mw::CPtr base, int has_base, int sign, int n)
+{
+  const int i = blockIdx.x * WG + threadIdx.x;
+  if(i >= n)
+    return;
+  Mw<NL> s = mw::load<NL>(out, i);
+  if(sign < 0)
+    s = mw::neg(s);
+  if(has_base)
+    s = mw::add(mw::load<NL>(base, i), s);
+  mw::store<NL>(out, i, s);
+}
+
+// Failure tags: stage << 27 | index, smallest wins (earliest stage, lowest block), so the error
+// that is raised does not depend on which rank or lane saw it first.  Stages follow the order
+// of the reference's throws: X, Y (cholesky_decomposition.cxx:22-25), S_j (compute_Q.cxx:36-38),
+// the normalised-Q diagonal (compute_Q.cxx:65-91), Cholesky(Q) (initialize_schur_complement_solver.cxx:99).
+enum FailStage : unsigned
+{
+  FAIL_X = 0,
+  FAIL_Y,
+  FAIL_S,
+  FAIL_QDIAG,
+  FAIL_Q
+};
+template <int UNUSED = 0> __global__ void __launch_bounds__(WG) k_fail_tags(const int *flags, int count, unsigned stage, int per_block, const BlockDesc *blk, uint32_t *tag)
+{
+  const int q = blockIdx.x * WG + threadIdx.x;
+  if(q >= count || !flags[q])
+    return;
+  const unsigned code = (unsigned)blk[q / per_block].global_index * (unsigned)per_block + (unsigned)(q % per_block);
+  atomicMin(tag, stage << 27 | code);
+}
+// qflags[0] = Cholesky(Q) failed, qflags[1] = 1 + first bad diagonal entry of the normalised Q
+template <int UNUSED = 0> __global__ void k_fail_tags_q(const int *qflags, uint32_t *tag)
+{
+  if(blockIdx.x || threadIdx.x)
+    return;
+  if(qflags[1])
+    atomicMin(tag, (unsigned)FAIL_QDIAG << 27 | (unsigned)(qflags[1] - 1));
+  else if(qflags[0])
+    atomicMin(tag, (unsigned)FAIL_Q << 27);
+}
+
+// Largest (max diag / min diag) over the Cholesky factors of S_j, X_jb, Y_jb in the reference's
+// scan order (update_cond_numbers.hxx:16-110: block, then S, X_0, Y_0, X_1, Y_1; the first
+// maximum wins).  ratio: [0,J1) S, [J1,3J1) X, [3J1,5J1) Y (k_diag_ratio).  Writes the value to
+// res[slot] and global_block*8 + kind*2 + parity + 1 (kind 0 S, 1 X, 2 Y; 0 = none) to *tagword.
+template <int NL>
+__global__ void __launch_bounds__(WG) k_cond_best(mw::CPtr ratio, int Jl, const BlockDesc *blk, mw::Ptr res, size_t slot, uint32_t *tagword)
+{
+  const int J1 = Jl > 0 ? Jl : 1, t = threadIdx.x;
+  constexpr int NONE = 0x7fffffff;
+  Mw<NL> best = mw::zero<NL>();
+  int bc = NONE;
+  for(int c = t; c < 5 * Jl; c += WG)
+    {
+      const int l = c / 5, k = c % 5;
+      const size_t pos = k == 0 ? (size_t)l : ((k & 1) ? (size_t)J1 + 2 * l + (k == 3) : (size_t)3 * J1 + 2 * l + (k == 4));
+      const Mw<NL> v = mw::load<NL>(ratio, pos);
+      if(!mw::is_zero(v) && (bc == NONE || mw::lt(best, v)))
+        {
+          best = v;
+          bc = c;
+        }
+    }
+  __shared__ Mw<NL> sv[WG];
+  __shared__ int sc[WG];
+  sv[t] = best;
+  sc[t] = bc;
+  __syncthreads();
+  for(int s = WG / 2; s > 0; s >>= 1)
+    {
+      if(t < s && sc[t + s] != NONE)
+        {
+          const int c = mw::cmp(sv[t], sv[t + s]);
+          if(sc[t] == NONE || c < 0 || (c == 0 && sc[t + s] < sc[t]))
+            {
+              sv[t] = sv[t + s];
+              sc[t] = sc[t + s];
+            }
+        }
+      __syncthreads();
+    }
+  if(t == 0)
+    {
+      mw::store<NL>(res, slot, sc[0] == NONE ? mw::zero<NL>() : sv[0]);
+      uint32_t tag = 0;
+      if(sc[0] != NONE)
+        {
+          const int l = sc[0] / 5, k = sc[0] % 5;
+          const int kind = k == 0 ? 0 : ((k & 1) ? 1 : 2), parity = (k == 3 || k == 4) ? 1 : 0;
+          tag = (uint32_t)blk[l].global_index * 8u + (uint32_t)kind * 2u + (uint32_t)parity + 1u;
+        }
+      *tagword = tag;
+    }
+}
+
 // ---- multi-GPU exchange images ----------------------------------------------
 // 32-bit two's-complement limbs widened to u64 lanes so that an integer SUM
 // all-reduce (RCCL ncclSum on uint64) adds the partial Q' of every GPU exactly;

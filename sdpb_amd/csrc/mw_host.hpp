@@ -255,4 +255,107 @@ template <int NL> std::string to_decimal(const Mw<NL> &a, int digits = 0)
   out += std::to_string(point);
   return out;
 }
+
+// ---- binary records in GMP's mpf_t layout ------------------------------------------
+// The binary side of the C ABI (include/sdpb_hip.h: *_mpf entry points): one number =
+// 2 + L 64-bit words, word 0 = (int64) _mp_size (signed count of used limbs, 0 = zero),
+// word 1 = (int64) _mp_exp (exponent in 64-bit limbs), words 2.. = _mp_d[0..L), least
+// significant limb first; value = sign * (sum_i d[i] 2^(64 i)) * 2^(64 (exp - |size|)),
+// i.e. exactly what a caller holding an mpf_t (El::BigFloat::gmp_float) can memcpy.
+template <int NL> Mw<NL> from_mpf_record(const uint64_t *rec, int limbs64)
+{
+  const long long size = (long long)rec[0], expl = (long long)rec[1];
+  long long n = size < 0 ? -size : size;
+  if(n > limbs64)
+    throw std::runtime_error("mpf record: |_mp_size| exceeds the record's limb count");
+  const uint64_t *d = rec + 2;
+  while(n > 0 && d[n - 1] == 0)
+    --n;
+  Mw<NL> r = zero<NL>();
+  if(n == 0)
+    return r;
+  const int z = __builtin_clzll(d[n - 1]);
+  // bit string d[n-1] .. d[0], shifted left by z, top 32 NL bits kept (truncation toward zero)
+  auto limb = [&](long long i) -> uint64_t { return (i >= 0 && i < n) ? d[i] : 0; };
+  for(int k = 0; k < NL; ++k)
+    {
+      // 32-bit word k counted from the top: bits [64n - 32(k+1) - z, +32) of the integer
+      const long long bit = 64 * n - 32LL * (k + 1) - z;
+      uint32_t w = 0;
+      if(bit > -32)
+        {
+          const long long q = bit >= 0 ? bit / 64 : -1, rbit = bit >= 0 ? bit % 64 : 0;
+          if(bit >= 0)
+            {
+              uint64_t v = limb(q) >> rbit;
+              if(rbit > 32)
+                v |= limb(q + 1) << (64 - rbit);
+              w = (uint32_t)v;
+            }
+          else
+            w = (uint32_t)(limb(0) << (-bit)); // the lowest word hangs over the end
+        }
+      r.m[NL - 1 - k] = w;
+    }
+  const long long e = 64 * expl - z + 64 * (n - (size < 0 ? -size : size));
+  if(e > (1LL << 29) || e < -(1LL << 29))
+    throw std::runtime_error("mpf record: exponent out of range");
+  r.e = (int32_t)e;
+  r.neg = size < 0 ? 1u : 0u;
+  return r;
+}
+// Exact when limbs64 >= NL/2 + 1 (GMP's own allocation _mp_prec + 1 for the same precision);
+// fewer limbs truncate the low bits.
+template <int NL> void to_mpf_record(const Mw<NL> &v, uint64_t *rec, int limbs64)
+{
+  for(int i = 0; i < limbs64 + 2; ++i)
+    rec[i] = 0;
+  if(v.e == EZERO)
+    return;
+  // value = 0.m * 2^e;  exp = ceil(e / 64), the mantissa is shifted right by s = 64 exp - e bits
+  const long long e = v.e;
+  const long long expl = e >= 0 ? (e + 63) / 64 : -((-e) / 64);
+  const int s = (int)(64 * expl - e); // 0..63
+  // fraction bits: s zeros, then the 32 NL bits of m; limb k from the top (k = 0 most significant)
+  auto frac_bit_word = [&](long long bit) -> uint64_t { // 64 bits starting `bit` bits below the binary point
+    uint64_t out = 0;
+    for(int b = 0; b < 64; b += 32)
+      {
+        // 32-bit chunk covering fraction bits [bit + b, bit + b + 32)
+        const long long pos = bit + b - s; // position inside m's bit string (0 = top bit)
+        uint32_t w = 0;
+        if(pos > -32 && pos < 32LL * NL)
+          {
+            const long long k = pos >= 0 ? pos / 32 : -1, r = pos >= 0 ? pos % 32 : 0;
+            if(pos >= 0)
+              {
+                const uint32_t hi = v.m[NL - 1 - k], lo = (k + 1 < NL) ? v.m[NL - 2 - k] : 0u;
+                w = r ? ((hi << r) | (lo >> (32 - r))) : hi;
+              }
+            else
+              w = v.m[NL - 1] >> (-pos);
+          }
+        out |= (uint64_t)w << (32 - b);
+      }
+    return out;
+  };
+  int used = 0;
+  for(int k = 0; k < limbs64; ++k)
+    {
+      const uint64_t w = frac_bit_word(64LL * k);
+      rec[2 + (limbs64 - 1 - k)] = w;
+      if(w)
+        used = k + 1;
+    }
+  // drop low zero limbs like mpf does: keep `used` limbs at the bottom of d[]
+  if(used < limbs64)
+    {
+      for(int k = 0; k < used; ++k)
+        rec[2 + k] = rec[2 + (limbs64 - used) + k];
+      for(int k = used; k < limbs64; ++k)
+        rec[2 + k] = 0;
+    }
+  rec[0] = (uint64_t)(long long)(v.neg ? -used : used);
+  rec[1] = (uint64_t)expl;
+}
 } // namespace mw

@@ -11,8 +11,10 @@
 #include "mw_host.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -39,6 +41,46 @@ struct Collectives
   void *user = nullptr;
 };
 
+// Cross-rank exchange behind one interface: stream-ordered from the caller's point of view.
+//   CallbackComm: host callbacks (MPI host, torch.distributed in the tests/launcher); the
+//                 stream is synchronised around the call.
+//   RcclComm:     RCCL inside the library (rccl_comm.hpp), enqueued on the library's stream —
+//                 no host synchronisation at all.
+struct Comm
+{
+  virtual ~Comm() {}
+  virtual void allgather(const void *dev_send, void *dev_recv, size_t bytes, hipStream_t st) = 0;
+  virtual void allreduce_sum_u64(void *dev_buf, size_t count, hipStream_t st) = 0;
+  virtual const char *name() const = 0;
+};
+struct CallbackComm : Comm
+{
+  Collectives c;
+  explicit CallbackComm(const Collectives &cc) : c(cc) {}
+  void allgather(const void *send, void *recv, size_t bytes, hipStream_t st) override
+  {
+    if(!c.allgather_bytes)
+      throw SolverError(4, "world_size > 1 but no all-gather callback was registered (sdpb_hip_set_collectives)");
+    HIP_CHECK(hipStreamSynchronize(st));
+    if(c.allgather_bytes(c.user, send, recv, bytes) != 0)
+      throw HipError(3, "allgather callback failed");
+  }
+  void allreduce_sum_u64(void *buf, size_t count, hipStream_t st) override
+  {
+    if(!c.allreduce_sum_u64)
+      throw SolverError(4, "world_size > 1 but no all-reduce callback was registered (sdpb_hip_set_collectives)");
+    HIP_CHECK(hipStreamSynchronize(st));
+    if(c.allreduce_sum_u64(c.user, buf, count) != 0)
+      throw HipError(3, "allreduce callback failed");
+  }
+  const char *name() const override { return "callbacks"; }
+};
+
+} // namespace sdpb
+#include "rccl_comm.hpp"
+namespace sdpb
+{
+
 enum TerminateReason // SDP_Solver_Terminate_Reason.hxx
 {
   NotTerminated = -1,
@@ -51,7 +93,8 @@ enum TerminateReason // SDP_Solver_Terminate_Reason.hxx
   MaxRuntimeExceeded,
   MaxComplementarityExceeded,
   PrimalStepTooSmall,
-  DualStepTooSmall
+  DualStepTooSmall,
+  SIGTERM_Received
 };
 inline const char *terminate_string(int r)
 {
@@ -64,8 +107,9 @@ inline const char *terminate_string(int r)
                                 "maxRuntime exceeded",
                                 "maxComplementarity exceeded",
                                 "primal step too small",
-                                "dual step too small"};
-  return (r < 0 || r > 9) ? "" : names[r];
+                                "dual step too small",
+                                "SIGTERM signal received"};
+  return (r < 0 || r > 10) ? "" : names[r];
 }
 
 // Static block -> GPU assignment: longest-processing-time greedy on an analytic
@@ -108,6 +152,11 @@ public:
   virtual void set_block(int j, const char *be, const char *bo, const char *B, const char *c) = 0;
   virtual void set_block_f64(int j, const char *be, const char *bo, const double *B, const double *c) = 0;
   virtual void set_objective(const char *b, const char *constant) = 0;
+  // binary flavour: records in mpf_t layout (mw_host.hpp: from_mpf_record), limbs64 limbs each
+  virtual void set_block_mpf(int j, int limbs64, const uint64_t *be, const uint64_t *bo, const uint64_t *B, const uint64_t *c) = 0;
+  virtual void set_objective_mpf(int limbs64, const uint64_t *b, const uint64_t *constant) = 0;
+  virtual size_t get_array_mpf(const std::string &which, int j, int parity, int limbs64, uint64_t *out, size_t capacity) = 0;
+  virtual void set_array_mpf(const std::string &which, int j, int parity, int limbs64, const uint64_t *values, size_t count) = 0;
   virtual void init_state() = 0;
   virtual bool iterate() = 0;
   virtual int terminate_reason() const = 0;
@@ -116,7 +165,13 @@ public:
   virtual void set_array(const std::string &which, int j, int parity, const char *txt) = 0;
   virtual int block_owner(int j) const = 0;
   virtual void set_collectives(const Collectives &c) = 0;
-  virtual std::string timers_json() const = 0;
+  virtual void init_rccl(const void *unique_id, size_t id_bytes) = 0;
+  virtual const char *comm_name() const = 0;
+  virtual void set_profiling(bool on) = 0;
+  virtual void set_max_runtime(double seconds) = 0;
+  virtual void request_stop() = 0;
+  virtual long host_syncs() const = 0;
+  virtual std::string timers_json() = 0;
   virtual int limbs() const = 0;
   virtual int fx_frac_bits() const = 0;
   virtual double bench_op(const std::string &op, int a, int b, int reps) = 0;
@@ -190,13 +245,45 @@ template <int NL> class Solver : public SolverBase
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_, eigD2_, eigE2_, cmby_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, lam2_, ratio_, scal_;
-  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, xsend_, xrecv_, colsum_partial_, syrk_part_;
+  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, colsum_partial_, syrk_part_;
   int num_cus_ = 256;
   unsigned colsum_slices_ = 1;
   DevBuf<double> eigF_, eigF2_;
   DevBuf<unsigned long long> acc64_;
-  DevBuf<int> flags_; // [0..2Jl) chol fail per psd/schur matrix, then Q fail, Q diag fail
+  DevBuf<int> flags_; // [0..2Jl) chol fail per psd (X) matrix, then Q fail, Q diag fail
   DevBuf<int> flags2_; // chol fail of Y (factored on the side stream concurrently with X)
+  DevBuf<int> flags3_; // chol fail of the Schur blocks S_j
+  // Result block (kernels.hpp: XOp): R_COUNT numbers + X_EXTRA words.  Reductions deposit their
+  // results here; the host reads the whole block with one copy at each of the three
+  // synchronisation points of an iteration (fetch()).
+  enum ResSlot
+  {
+    R_CX = 0,
+    R_BY,
+    R_DERR,
+    R_PERR_P,
+    R_PERR_p,
+    R_TRACE,
+    R_RERR,
+    R_FROB,
+    R_LAMX,
+    R_LAMY,
+    R_COND,
+    R_QCOND,
+    R_COUNT
+  };
+  static_assert(R_COUNT <= X_MAXSLOTS, "result block too large for XOps");
+  static constexpr size_t RES_WORDS = (size_t)(NL + 1) * R_COUNT + X_EXTRA;
+  DevBuf<uint32_t> resbuf_, xgather_;
+  std::vector<M> res_host_ = std::vector<M>(R_COUNT);
+  uint32_t xw_host_[X_EXTRA] = {0xffffffffu, 0, 0, 0};
+  std::unique_ptr<Comm> comm_;
+  long host_syncs_ = 0;
+  bool profile_ = false;
+  double max_runtime_s_ = std::numeric_limits<double>::infinity();
+  std::chrono::steady_clock::time_point start_time_;
+  bool started_ = false;
+  std::atomic<int> stop_requested_{0};
   size_t fx_stride_ = 0, acc_stride_ = 0;
 
   // ---- parameters (Solver_Parameters.hxx:13-30) --------------------------------
@@ -219,6 +306,7 @@ template <int NL> class Solver : public SolverBase
   hipStream_t stream_q2_ = nullptr; // bulk updates of the look-ahead Cholesky(Q)
   bool q_pending_ = false;
   hipEvent_t ev_syrk0_ = nullptr, ev_syrk1_ = nullptr;
+  bool syrk_events_pending_ = false;
   double syrk_kernel_ms_ = 0;
   long syrk_launches_ = 0;
   std::map<std::string, double> timers_ms_;
@@ -283,7 +371,22 @@ public:
   int limbs() const override { return NL; }
   int fx_frac_bits() const override { return sdpb::fx_frac_bits<FX>(); }
   int block_owner(int j) const override { return owner_.at(j); }
-  void set_collectives(const Collectives &c) override { coll_ = c; }
+  void set_collectives(const Collectives &c) override
+  {
+    coll_ = c;
+    comm_.reset(new CallbackComm(c));
+  }
+  void init_rccl(const void *unique_id, size_t id_bytes) override
+  {
+    if(world_ == 1)
+      return;
+    comm_.reset(make_rccl_comm(unique_id, id_bytes, rank_, world_));
+  }
+  const char *comm_name() const override { return world_ == 1 ? "none" : (comm_ ? comm_->name() : "unset"); }
+  void set_profiling(bool on) override { profile_ = on; }
+  void set_max_runtime(double seconds) override { max_runtime_s_ = seconds; }
+  void request_stop() override { stop_requested_.store(1); } // async-signal-safe: a SIGTERM handler may call it
+  long host_syncs() const override { return host_syncs_; }
   int terminate_reason() const override { return terminate_reason_; }
 
 private:
@@ -419,11 +522,15 @@ private:
     if(world_ > 1)
       {
         acc64_.alloc(acc_stride_ * ACCW);
-        xsend_.alloc((size_t)(NL + 2) * std::max(N_, 16));
-        xrecv_.alloc((size_t)(NL + 2) * std::max(N_, 16) * world_);
       }
     flags_.alloc((size_t)2 * std::max(Jl_, 1) + 4);
     flags2_.alloc((size_t)2 * std::max(Jl_, 1));
+    flags3_.alloc((size_t)std::max(Jl_, 1));
+    resbuf_.alloc(RES_WORDS);
+    if(world_ > 1)
+      xgather_.alloc(std::max(RES_WORDS, (size_t)(NL + 1) * N_) * world_);
+    if(const char *e = std::getenv("SDPB_HIP_PROFILE"))
+      profile_ = std::atoi(e) != 0;
   }
 
   void set_default_params()
@@ -461,12 +568,20 @@ private:
     Solver *s;
     std::string name;
     std::chrono::steady_clock::time_point t0;
-    Timer(Solver *s_, const std::string &n) : s(s_), name(n)
+    // Stage timers synchronise the stream, so they exist only when profiling is requested
+    // (SDPB_HIP_PROFILE=1 / sdpb_hip_set_profiling); the reference pays for its timers at
+    // --verbosity >= 2 only.  Unprofiled iterations queue their launches ahead of the GPU.
+    Timer(Solver *s_, const char *n) : s(s_)
     {
+      if(!s->profile_)
+        return;
+      name = n;
       t0 = std::chrono::steady_clock::now();
     }
     ~Timer()
     {
+      if(!s->profile_ || name.empty())
+        return;
       (void)hipStreamSynchronize(s->stream_);
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if(!s->timers_ms_.count(name))
@@ -476,8 +591,10 @@ private:
   };
 
 public:
-  std::string timers_json() const override
+  std::string timers_json() override
   {
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    resolve_syrk_events();
     std::ostringstream ss;
     ss << "{";
     bool first = true;
@@ -492,7 +609,8 @@ public:
        << ", \"kernel.k_syrk_fx.algorithmic_bytes\": " << (fx_bytes + acc_bytes)
        << ", \"kernel.k_syrk_fx.limb_macs\": "
        << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 9 (FX/4)^2 or 3 (FX/2)^2 per product
-       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TWO_LEVEL ? 2 : 1);
+       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TWO_LEVEL ? 2 : 1) << ", \"host_syncs\": " << host_syncs_
+       << ", \"iterations\": " << iteration_;
     ss << "}";
     return ss.str();
   }
@@ -574,6 +692,41 @@ public:
       v[i] = mw::from_double<NL>(c[i]);
     upload<NL>(c_, bd.voff, v);
   }
+  static std::vector<M> records(const uint64_t *rec, size_t count, int limbs64)
+  {
+    if(!rec || limbs64 < 1)
+      throw SolverError(4, "mpf records: null pointer or limbs64 < 1");
+    std::vector<M> v(count);
+    try
+      {
+        for(size_t i = 0; i < count; ++i)
+          v[i] = mw::from_mpf_record<NL>(rec + i * (size_t)(limbs64 + 2), limbs64);
+      }
+    catch(std::exception &e)
+      {
+        throw SolverError(4, e.what());
+      }
+    return v;
+  }
+  // Same as set_block with every number given as an mpf_t-layout record (row-major like the JSON)
+  void set_block_mpf(int j, int limbs64, const uint64_t *be, const uint64_t *bo, const uint64_t *B, const uint64_t *c) override
+  {
+    if(j < 0 || j >= J_)
+      throw SolverError(4, "set_block: block index out of range");
+    const int l = local_index(j);
+    if(l < 0)
+      return;
+    const BlockDesc &bd = blk_[l];
+    const std::vector<M> e = records(be, (size_t)bd.rows[0] * bd.K, limbs64), o = records(bo, (size_t)bd.rows[1] * bd.K, limbs64);
+    set_block_bases_values(l, e, o);
+    upload<NL>(BT_, h_bt_[l].off, records(B, (size_t)bd.P * N_, limbs64));
+    upload<NL>(c_, bd.voff, records(c, bd.P, limbs64));
+  }
+  void set_objective_mpf(int limbs64, const uint64_t *b, const uint64_t *constant) override
+  {
+    upload<NL>(b_, 0, records(b, N_, limbs64));
+    objective_const_ = records(constant, 1, limbs64)[0];
+  }
   int set_block_bases(int j, const char *be, const char *bo)
   {
     if(j < 0 || j >= J_)
@@ -582,11 +735,19 @@ public:
     if(l < 0)
       return -1;
     const BlockDesc &bd = blk_[l];
-    const char *src[2] = {be, bo};
+    set_block_bases_values(l, parse_list(be, (size_t)bd.rows[0] * bd.K, "bilinear_bases"), parse_list(bo, (size_t)bd.rows[1] * bd.K, "bilinear_bases"));
+    return l;
+  }
+  // bases given row-major (rows[b] x K) for the two parities of local block l
+  void set_block_bases_values(int l, const std::vector<M> &even, const std::vector<M> &odd)
+  {
+    const BlockDesc &bd = blk_[l];
+    const std::vector<M> *src[2] = {&even, &odd};
     for(int b = 0; b < 2; ++b)
       {
         const int rs = bd.rows[b];
-        std::vector<M> v = parse_list(src[b], (size_t)rs * bd.K, "bilinear_bases"), cm((size_t)rs * bd.K);
+        const std::vector<M> &v = *src[b];
+        std::vector<M> cm((size_t)rs * bd.K);
         for(int r = 0; r < rs; ++r)
           for(int k = 0; k < bd.K; ++k)
             cm[(size_t)k * rs + r] = v[(size_t)r * bd.K + k];
@@ -601,7 +762,6 @@ public:
     const size_t mx = std::max((size_t)bd.n[0] * bd.m * bd.K, (size_t)bd.n[1] * bd.m * bd.K);
     launch(k_build_bases_block<NL>, dim3(cdiv(mx, WG), 2), dim3(WG), stream_, bb, ee, et, d_blk_.p + l);
     HIP_CHECK(hipStreamSynchronize(stream_));
-    return l;
   }
   void set_objective(const char *b, const char *constant) override
   {
@@ -619,6 +779,7 @@ public:
     add_diagonal(X_, S_ALPHA_P);
     add_diagonal(Y_, S_ALPHA_D);
     iteration_ = 0;
+    started_ = false;
     terminate_reason_ = NotTerminated;
     primal_step_length_ = mw::zero<NL>();
     dual_step_length_ = mw::zero<NL>();
@@ -629,7 +790,11 @@ private:
   // ==========================================================================
   // small device helpers
   // ==========================================================================
-  void upload_scalar(int slot, const M &v) { upload<NL>(scal_, slot, std::vector<M>{v}); }
+  mw::Ptr res() const { return mw::Ptr{resbuf_.p, (size_t)R_COUNT}; }
+  uint32_t *xwords() const { return resbuf_.p + (size_t)(NL + 1) * R_COUNT; }
+  // a host scalar travels as a kernel argument: stream ordered, no copy, no synchronisation
+  void store_scalar(mw::Ptr p, size_t idx, const M &v) { launch(k_store_scalar<NL>, dim3(1), dim3(64), stream_, p, idx, v); }
+  void upload_scalar(int slot, const M &v) { store_scalar(scal_.ptr(), (size_t)slot, v); }
 
   template <class F> void foreach(size_t count, F f)
   {
@@ -637,86 +802,124 @@ private:
       return;
     launch(k_foreach<F>, dim3(std::min<unsigned>(cdiv(count, WG), 4096)), dim3(WG), stream_, count, f);
   }
-  // two-stage reduction; returns the value on the host.  Empty range -> 0.
-  template <int OP, class F> M reduce(size_t count, F f)
+  // two-stage reduction into result slot `slot` (no synchronisation).  Empty range -> `empty`.
+  template <int OP, class F> void reduce_to(int slot, size_t count, F f, const M &empty = mw::zero<NL>())
   {
     if(!count)
-      return mw::zero<NL>();
+      {
+        store_scalar(res(), (size_t)slot, empty);
+        return;
+      }
     const unsigned g = std::min<unsigned>(cdiv(count, WG), 512);
     launch(k_reduce<NL, OP, F>, dim3(g), dim3(WG), stream_, count, f, red_.ptr());
     mw::CPtr rp = red_.cptr();
     auto ld = [rp] __device__(size_t i) { return mw::load<NL>(rp, i); };
-    launch(k_reduce<NL, OP, decltype(ld)>, dim3(1), dim3(WG), stream_, (size_t)g, ld, red2_.ptr());
+    launch(k_reduce<NL, OP, decltype(ld)>, dim3(1), dim3(WG), stream_, (size_t)g, ld, mw::Ptr{resbuf_.p + slot, (size_t)R_COUNT});
+  }
+  Comm &comm()
+  {
+    if(!comm_)
+      throw SolverError(4, "world_size > 1 but no collectives were registered (sdpb_hip_set_collectives / sdpb_hip_rccl_init)");
+    return *comm_;
+  }
+  // All-gather the result blocks of every rank and combine slot by slot in rank order (every rank
+  // ends with identical bits, so ranks stay in lock-step).  One message per synchronisation point.
+  void exchange(std::initializer_list<std::pair<int, int>> slot_ops)
+  {
+    if(world_ == 1)
+      return;
+    XOps ops;
+    for(int &o : ops.op)
+      o = X_KEEP;
+    for(auto &so : slot_ops)
+      ops.op[so.first] = so.second;
+    comm().allgather(resbuf_.p, xgather_.p, RES_WORDS * sizeof(uint32_t), stream_);
+    launch(k_combine_slots<NL>, dim3(1), dim3(64), stream_, (const uint32_t *)xgather_.p, world_, (int)R_COUNT, ops, resbuf_.p);
+  }
+  // THE synchronisation point: one copy of the result block, then the host decides.
+  void fetch()
+  {
+    uint32_t h[RES_WORDS];
+    HIP_CHECK(hipMemcpyAsync(h, resbuf_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
-    return download<NL>(red2_, 0, 1)[0];
-  }
-  // cross-rank combination of a host scalar (all ranks end with identical bits)
-  M allreduce_scalar(const M &v, int op)
-  {
-    if(world_ == 1)
-      return v;
-    std::vector<M> all = allgather(std::vector<M>{v});
-    M r = all[0];
-    for(int k = 1; k < world_; ++k)
-      r = op == RED_SUM ? mw::add(r, all[k]) : (op == RED_MAX ? mw::max(r, all[k]) : mw::min(r, all[k]));
-    return r;
-  }
-  // gather a short host vector from every rank (rank order)
-  std::vector<M> allgather(const std::vector<M> &v)
-  {
-    if(world_ == 1)
-      return v;
-    if(!coll_.allgather_bytes)
-      throw SolverError(4, "world_size > 1 but no collectives were registered (sdpb_hip_set_collectives)");
-    const size_t words = (size_t)(NL + 2) * v.size();
-    // persistent exchange buffers: hipMalloc/hipFree would synchronise the whole device,
-    // including the stream that factors Q concurrently
-    if(xsend_.n < words || xrecv_.n < words * world_)
+    host_syncs_ += 1;
+    for(int i = 0; i < R_COUNT; ++i)
       {
-        HIP_CHECK(hipDeviceSynchronize());
-        xsend_.alloc(words);
-        xrecv_.alloc(words * world_);
-      }
-    DevBuf<uint32_t> &send = xsend_, &recv = xrecv_;
-    std::vector<uint32_t> h(words);
-    for(size_t i = 0; i < v.size(); ++i)
-      {
-        h[i * (NL + 2)] = (uint32_t)v[i].e;
-        h[i * (NL + 2) + 1] = v[i].neg;
+        const uint32_t hd = h[i];
+        res_host_[i].neg = hd >> 31;
+        res_host_[i].e = hd ? (int32_t)((hd & 0x7fffffffu) - mw::EBIAS) : mw::EZERO;
         for(int k = 0; k < NL; ++k)
-          h[i * (NL + 2) + 2 + k] = v[i].m[k];
+          res_host_[i].m[k] = h[(size_t)(k + 1) * R_COUNT + i];
       }
-    HIP_CHECK(hipMemcpy(send.p, h.data(), words * 4, hipMemcpyHostToDevice));
-    if(coll_.allgather_bytes(coll_.user, send.p, recv.p, words * 4) != 0)
-      throw HipError(3, "allgather callback failed");
-    std::vector<uint32_t> g(words * world_);
-    HIP_CHECK(hipMemcpy(g.data(), recv.p, g.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<M> out(v.size() * world_);
-    for(size_t i = 0; i < out.size(); ++i)
-      {
-        out[i].e = (int32_t)g[i * (NL + 2)];
-        out[i].neg = g[i * (NL + 2) + 1];
-        for(int k = 0; k < NL; ++k)
-          out[i].m[k] = g[i * (NL + 2) + 2 + k];
-      }
-    return out;
+    for(int k = 0; k < X_EXTRA; ++k)
+      xw_host_[k] = h[(size_t)(NL + 1) * R_COUNT + k];
+    throw_if_failed();
   }
-  // Sum an N-vector held in a device array across ranks (deterministic: gathered and
-  // added in rank order on every rank).
+  // the reference's RUNTIME_ERRORs, from the smallest failure tag of all ranks
+  void throw_if_failed()
+  {
+    const uint32_t tag = xw_host_[XW_FAIL];
+    if(tag == 0xffffffffu)
+      return;
+    // leave the streams quiet before unwinding (the side streams may still be busy)
+    (void)hipStreamSynchronize(stream_q_);
+    (void)hipStreamSynchronize(stream_q2_);
+    q_pending_ = false;
+    const unsigned stage = tag >> 27, code = tag & ((1u << 27) - 1u);
+    std::ostringstream ss;
+    switch(stage)
+      {
+      case FAIL_X:
+      case FAIL_Y: // cholesky_decomposition.cxx:22-25
+        ss << "Error when computing Cholesky decomposition of Block_Diagonal_Matrix " << (stage == FAIL_X ? "X" : "Y")
+           << ", block index = " << code / 2 << ", parity = " << code % 2 << ": A was not numerically HPD";
+        break;
+      case FAIL_S: // compute_Q.cxx:36-38
+        ss << "Error when computing Cholesky decomposition of block_" << code << ": A was not numerically HPD";
+        break;
+      case FAIL_QDIAG: // compute_Q.cxx:65-91
+        ss << "Normalized Q should have ones on diagonal. For i = " << code;
+        break;
+      default: // initialize_schur_complement_solver.cxx:95-103
+        ss << "Error when computing Cholesky(Q): A was not numerically HPD";
+      }
+    throw SolverError(1, ss.str());
+  }
+  // Sum an N-vector held in a device array (stride == count) across ranks: gathered and added in
+  // rank order by every rank (bit-identical results everywhere), entirely on the device.
   void allreduce_vec_sum(DevArray &a, size_t count)
   {
     if(world_ == 1)
       return;
-    std::vector<M> mine = download<NL>(a, 0, count);
-    std::vector<M> all = allgather(mine);
-    for(size_t i = 0; i < count; ++i)
+    if(a.n != count)
+      throw SolverError(4, "allreduce_vec_sum: array stride differs from the vector length");
+    const size_t words = (size_t)(NL + 1) * count;
+    if(xgather_.n < words * world_)
       {
-        M s = all[i];
-        for(int k = 1; k < world_; ++k)
-          s = mw::add(s, all[(size_t)k * count + i]);
-        mine[i] = s;
+        HIP_CHECK(hipDeviceSynchronize());
+        xgather_.alloc(words * world_);
       }
-    upload<NL>(a, 0, mine);
+    comm().allgather(a.base, xgather_.p, words * sizeof(uint32_t), stream_);
+    launch(k_combine_vec<NL>, dim3(cdiv(count, WG)), dim3(WG), stream_, (const uint32_t *)xgather_.p, world_, (int)count, a.ptr());
+  }
+  // streams are exchanged for a scope (exception safe)
+  struct OnSideStream
+  {
+    Solver *s;
+    explicit OnSideStream(Solver *s_) : s(s_) { std::swap(s->stream_, s->stream_q_); }
+    ~OnSideStream() { std::swap(s->stream_, s->stream_q_); }
+  };
+  void resolve_syrk_events()
+  {
+    if(!syrk_events_pending_)
+      return;
+    syrk_events_pending_ = false;
+    float ms = 0;
+    if(hipEventElapsedTime(&ms, ev_syrk0_, ev_syrk1_) == hipSuccess)
+      {
+        syrk_kernel_ms_ += ms;
+        syrk_launches_ += 1;
+      }
   }
 
   void copy(const DevArray &src, DevArray &dst)
@@ -746,25 +949,6 @@ private:
   {
     launch(k_symmetrize<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(A), (int)negate);
   }
-  void check_chol_flags(int count, const char *what, bool schur) { check_chol_flags(count, what, schur, flags_); }
-  void check_chol_flags(int count, const char *what, bool schur, DevBuf<int> &flags)
-  {
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    std::vector<int> f = flags.download();
-    for(int q = 0; q < count; ++q)
-      if(f[q])
-        {
-          std::ostringstream ss;
-          if(schur) // compute_Q.cxx:36-38
-            ss << "Error when computing Cholesky decomposition of block_" << local_[q] << ": A was not numerically HPD";
-          else // cholesky_decomposition.cxx:22-25
-            ss << "Error when computing Cholesky decomposition of Block_Diagonal_Matrix " << what
-               << ", block index = " << local_[q / 2] << ", parity = " << q % 2 << ": A was not numerically HPD";
-          throw SolverError(1, ss.str());
-        }
-  }
-  void clear_flags() { HIP_CHECK(hipMemsetAsync(flags_.p, 0, flags_.n * sizeof(int), stream_)); }
-
   // A = L L^T in place for a batch (lower factor; Li receives the inverted diagonal blocks)
   void blocked_cholesky(const Batch &A, const Batch &invd, const Batch &Li, int max_n, int *fail, hipStream_t st = nullptr)
   {
@@ -854,18 +1038,13 @@ private:
   // ==========================================================================
   // the iteration
   // ==========================================================================
-  // compute_objectives.cxx:6-29, dot.cxx:4-22
-  void compute_objectives()
+  // compute_objectives.cxx:6-29, dot.cxx:4-22: the two dot products (combined on the host after fetch())
+  void queue_objectives()
   {
     Timer t(this, "objectives");
     mw::CPtr c = c_.cptr(), x = x_.cptr(), b = b_.cptr(), y = y_.cptr();
-    M cx = reduce<RED_SUM>(Ptot_, [=] __device__(size_t i) { return mw::mul(mw::load<NL>(c, i), mw::load<NL>(x, i)); });
-    cx = allreduce_scalar(cx, RED_SUM);
-    const M by = reduce<RED_SUM>((size_t)N_, [=] __device__(size_t i) { return mw::mul(mw::load<NL>(b, i), mw::load<NL>(y, i)); });
-    primal_objective_ = mw::add(objective_const_, cx);
-    dual_objective_ = mw::add(objective_const_, by);
-    const M denom = mw::max(mw::add(mw::abs(primal_objective_), mw::abs(dual_objective_)), mw::from_u32<NL>(1));
-    duality_gap_ = mw::div(mw::abs(mw::sub(primal_objective_, dual_objective_)), denom);
+    reduce_to<RED_SUM>(R_CX, Ptot_, [=] __device__(size_t i) { return mw::mul(mw::load<NL>(c, i), mw::load<NL>(x, i)); });
+    reduce_to<RED_SUM>(R_BY, (size_t)N_, [=] __device__(size_t i) { return mw::mul(mw::load<NL>(b, i), mw::load<NL>(y, i)); });
   }
 
   // compute_bilinear_pairings.cxx:17-31
@@ -875,7 +1054,8 @@ private:
     compute_A_X_inv();
     // A_Y and the factor of Y were queued on the side stream by factor_X_and_Y()
     HIP_CHECK(hipStreamWaitEvent(stream_, ev_q_done_, 0));
-    check_chol_flags(2 * Jl_, "Y", false, flags2_);
+    if(Jl_)
+      launch(k_fail_tags<0>, dim3(cdiv(2 * Jl_, WG)), dim3(WG), stream_, (const int *)flags2_.p, 2 * Jl_, (unsigned)FAIL_Y, 2, d_blk_.p, xwords() + XW_FAIL);
   }
   // A_X_inv = (Xc^{-1} E)^T (Xc^{-1} E)      compute_A_X_inv.cxx:18-29
   // computed on the transpose: Tt = E^T Xc^{-T} (row solves), A_X_inv = Tt Tt^T
@@ -896,29 +1076,33 @@ private:
   }
   // cholesky_decomposition.cxx:5-28 for X and Y (run.cxx:386-387).  The factor of a batch of
   // small matrices is a latency-bound chain of pivots, so Y's factor and A_Y (which needs
-  // only Y) go to the side stream while X's factor and A_X_inv run on the main stream.
+  // only Y) go to the side stream while X's factor and A_X_inv run on the main stream.  A
+  // failed factorisation is recorded as a failure tag and raised at the next fetch().
   void factor_X_and_Y()
   {
     Timer t(this, "choleskyDecomposition");
     HIP_CHECK(hipMemsetAsync(flags_.p, 0, flags_.n * sizeof(int), stream_));
     HIP_CHECK(hipMemsetAsync(flags2_.p, 0, flags2_.n * sizeof(int), stream_));
+    HIP_CHECK(hipMemsetAsync(flags3_.p, 0, flags3_.n * sizeof(int), stream_));
     HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
     HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
-    std::swap(stream_, stream_q_);
-    copy(Y_, Yc_);
-    blocked_cholesky(psd(Yc_), vecn(invdY_), psd(LiY_), max_n_, flags2_.p);
-    compute_A_Y();
-    HIP_CHECK(hipEventRecord(ev_q_done_, stream_));
-    std::swap(stream_, stream_q_);
+    {
+      OnSideStream side(this);
+      copy(Y_, Yc_);
+      blocked_cholesky(psd(Yc_), vecn(invdY_), psd(LiY_), max_n_, flags2_.p);
+      compute_A_Y();
+      HIP_CHECK(hipEventRecord(ev_q_done_, stream_));
+    }
     copy(X_, Xc_);
     blocked_cholesky(psd(Xc_), vecn(invdX_), psd(LiX_), max_n_, flags_.p);
-    check_chol_flags(2 * Jl_, "X", false, flags_);
+    if(Jl_)
+      launch(k_fail_tags<0>, dim3(cdiv(2 * Jl_, WG)), dim3(WG), stream_, (const int *)flags_.p, 2 * Jl_, (unsigned)FAIL_X, 2, d_blk_.p, xwords() + XW_FAIL);
   }
 
-  M max_abs(const DevArray &a, size_t count)
+  void max_abs_to(int slot, const DevArray &a, size_t count)
   {
     mw::CPtr p = a.cptr();
-    return reduce<RED_MAX>(count, [=] __device__(size_t i) { return mw::abs(mw::load<NL>(p, i)); });
+    reduce_to<RED_MAX>(slot, count, [=] __device__(size_t i) { return mw::abs(mw::load<NL>(p, i)); });
   }
 
   // compute_dual_residues_and_error.cxx:7-66
@@ -927,7 +1111,7 @@ private:
     Timer t(this, "computeDualResidues");
     launch(k_dual_residues<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, pairB(AY_), c_.cptr(), dres_.ptr(), d_blk_.p);
     launch(k_gemv_n<NL>, dim3(cdiv(max_P_, 4), Jl_), dim3(WG), stream_, btB(BT_), y_.cptr(), dres_.ptr(), d_blk_.p, N_, -1);
-    dual_error_ = allreduce_scalar(max_abs(dres_, Ptot_), RED_MAX);
+    max_abs_to(R_DERR, dres_, Ptot_);
   }
   // constraint_matrix_weighted_sum.cxx:14-66 (+ the add/subtract that follows it)
   void constraint_matrix_weighted_sum(const DevArray &a, DevArray &out, const DevArray &addend, int sign)
@@ -940,7 +1124,7 @@ private:
   {
     Timer t(this, "computePrimalResidues");
     constraint_matrix_weighted_sum(x_, PR_, X_, -1);
-    primal_error_P_ = allreduce_scalar(max_abs(PR_, psd_elems_), RED_MAX);
+    max_abs_to(R_PERR_P, PR_, psd_elems_);
   }
   // out[n] = base[n] + sign * sum_blocks (M_j^T v_j)[n], summed over all ranks
   template <bool SQUARE> void gemv_t_all(const DevArray &MT, const DevArray &v, const DevArray *base, int sign, DevArray &out)
@@ -954,31 +1138,20 @@ private:
       }
     // local sum, cross-rank sum, then base + sign*sum
     launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part_.cptr(), Jl_, N_, out.cptr(), 0, 1, out.ptr());
-    HIP_CHECK(hipStreamSynchronize(stream_));
     allreduce_vec_sum(out, N_);
-    mw::Ptr o = out.ptr();
-    mw::CPtr bs = base ? base->cptr() : out.cptr();
-    const int has = base ? 1 : 0, sg = sign;
-    foreach((size_t)N_, [=] __device__(size_t i) {
-      M s = mw::load<NL>(o, i);
-      if(sg < 0)
-        s = mw::neg(s);
-      if(has)
-        s = mw::add(mw::load<NL>(bs, i), s);
-      mw::store<NL>(o, i, s);
-    });
+    launch(k_base_plus_signed<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, out.ptr(), base ? base->cptr() : out.cptr(), base ? 1 : 0, sign, N_);
   }
   // compute_primal_residues_and_error_p_b_Bx.cxx:9-86
   void compute_primal_residue_p()
   {
     Timer t(this, "computePrimalResidue_p");
     gemv_t_all<false>(BT_, x_, &b_, -1, rp_);
-    primal_error_p_ = max_abs(rp_, N_);
+    max_abs_to(R_PERR_p, rp_, N_);
   }
 
-  // compute_feasible_and_termination.cxx:4-71 (no wall-clock reason here: maxRuntime
-  // belongs to the caller's loop)
-  bool compute_feasible_and_termination(bool &feasible)
+  // compute_feasible_and_termination.cxx:4-71; `time_up` is rank 0's wall-clock test
+  // (":66-69 Time varies between cores, so follow the decision of the root")
+  bool compute_feasible_and_termination(bool &feasible, bool time_up)
   {
     const M perr = mw::max(primal_error_P_, primal_error_p_);
     const bool dualf = mw::lt(dual_error_, dual_error_threshold_), primf = mw::lt(perr, primal_error_threshold_);
@@ -997,6 +1170,8 @@ private:
       terminate_reason_ = PrimalFeasibleJumpDetected;
     else if(iteration_ > max_iterations_)
       terminate_reason_ = MaxIterationsExceeded;
+    else if(time_up)
+      terminate_reason_ = MaxRuntimeExceeded;
     else if(iteration_ > 1 && mw::lt(primal_step_length_, min_primal_step_))
       terminate_reason_ = PrimalStepTooSmall;
     else if(iteration_ > 1 && mw::lt(dual_step_length_, min_dual_step_))
@@ -1017,9 +1192,9 @@ private:
     {
       // compute_Q.cxx:9-61 : L = chol(S) in place, P^T = B^T L^{-T}
       Timer t(this, "initializeSchurComplementSolver.Q.cholesky");
-      clear_flags();
-      blocked_cholesky(schurB(), vecPB(invdS_), Batch{LiS_.ptr(), d_schur_.p, Jl_}, max_P_, flags_.p);
-      check_chol_flags(Jl_, "S", true);
+      blocked_cholesky(schurB(), vecPB(invdS_), Batch{LiS_.ptr(), d_schur_.p, Jl_}, max_P_, flags3_.p);
+      if(Jl_)
+        launch(k_fail_tags<0>, dim3(cdiv(Jl_, WG)), dim3(WG), stream_, (const int *)flags3_.p, Jl_, (unsigned)FAIL_S, 1, d_blk_.p, xwords() + XW_FAIL);
     }
     {
       Timer t(this, "initializeSchurComplementSolver.Q.solve");
@@ -1054,15 +1229,13 @@ private:
       if(cnt)
         {
           syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_);
-          // HIP events on the launch stream bracket the dominant kernel (bench.py roofline)
+          // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); they are
+          // read back lazily, after a later synchronisation point has passed them
+          resolve_syrk_events();
           HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
           syrk_G(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, (const uint32_t *)syrk_tiles_.p, syrk_part_);
           HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
-          HIP_CHECK(hipEventSynchronize(ev_syrk1_));
-          float ms = 0;
-          HIP_CHECK(hipEventElapsedTime(&ms, ev_syrk0_, ev_syrk1_));
-          syrk_kernel_ms_ += ms;
-          syrk_launches_ += 1;
+          syrk_events_pending_ = true;
         }
       else
         HIP_CHECK(hipMemsetAsync(acc_.p, 0, acc_.n * sizeof(uint32_t), stream_));
@@ -1119,13 +1292,9 @@ private:
   // exact cross-GPU sum of the fixed-point Q' images
   void reduce_Q_accumulators()
   {
-    if(!coll_.allreduce_sum_u64)
-      throw SolverError(4, "world_size > 1 but no collectives were registered (sdpb_hip_set_collectives)");
     const size_t words = acc_stride_ * ACCW;
     launch(k_widen_u64<0>, dim3(std::min<unsigned>(cdiv(words, WG), 8192)), dim3(WG), stream_, (const uint32_t *)acc_.p, words, acc64_.p);
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    if(coll_.allreduce_sum_u64(coll_.user, acc64_.p, words) != 0)
-      throw HipError(3, "allreduce callback failed");
+    comm().allreduce_sum_u64(acc64_.p, words, stream_);
     launch(k_narrow_carry<0>, dim3(std::min<unsigned>(cdiv(acc_stride_, WG), 8192)), dim3(WG), stream_, (const unsigned long long *)acc64_.p,
            acc_stride_, ACCW, acc_.p);
   }
@@ -1144,6 +1313,7 @@ private:
     HIP_CHECK(hipEventRecord(ev_q_done_, stream_q_));
     q_pending_ = true;
   }
+  // the main stream waits for the factor of Q (device-side); failures become tags
   void join_cholesky_Q()
   {
     if(!q_pending_)
@@ -1151,13 +1321,7 @@ private:
     q_pending_ = false;
     Timer t(this, "initializeSchurComplementSolver.Cholesky_Q(join)");
     HIP_CHECK(hipStreamWaitEvent(stream_, ev_q_done_, 0));
-    HIP_CHECK(hipEventSynchronize(ev_q_done_));
-    int f[4];
-    HIP_CHECK(hipMemcpy(f, flags_.p + 2 * std::max(Jl_, 1), sizeof f, hipMemcpyDeviceToHost));
-    if(f[1])
-      throw SolverError(1, "Normalized Q should have ones on diagonal. For i = " + std::to_string(f[1] - 1));
-    if(f[0])
-      throw SolverError(1, "Error when computing Cholesky(Q): A was not numerically HPD");
+    launch(k_fail_tags_q<0>, dim3(1), dim3(64), stream_, (const int *)(flags_.p + 2 * std::max(Jl_, 1)), xwords() + XW_FAIL);
   }
 
   // solve_schur_complement_equation.cxx:16-79
@@ -1238,15 +1402,18 @@ private:
       symmetrize(dY_, true);
     }
   }
-  // corrector_centering_parameter.cxx:12-31 + frobenius_product_of_sums.cxx:6-31
-  M corrector_centering_parameter(bool feasible)
+  // frobenius_product_of_sums.cxx:6-31: sum (X+dX).(Y+dY) into R_FROB
+  void queue_frobenius_product()
   {
     mw::CPtr X = X_.cptr(), dX = dX_.cptr(), Y = Y_.cptr(), dY = dY_.cptr();
-    M fr = reduce<RED_SUM>(psd_elems_, [=] __device__(size_t i) {
+    reduce_to<RED_SUM>(R_FROB, psd_elems_, [=] __device__(size_t i) {
       return mw::mul(mw::add(mw::load<NL>(X, i), mw::load<NL>(dX, i)), mw::add(mw::load<NL>(Y, i), mw::load<NL>(dY, i)));
     });
-    fr = allreduce_scalar(fr, RED_SUM);
-    const M r = mw::div(fr, mw::mul(mu_, mw::from_u32<NL>((uint32_t)total_psd_rows_)));
+  }
+  // corrector_centering_parameter.cxx:12-31 from the fetched Frobenius product
+  M corrector_centering_parameter(bool feasible)
+  {
+    const M r = mw::div(res_host_[R_FROB], mw::mul(mu_, mw::from_u32<NL>((uint32_t)total_psd_rows_)));
     const M one = mw::from_u32<NL>(1);
     const M beta = mw::lt(r, one) ? mw::mul(r, r) : r;
     if(feasible)
@@ -1272,44 +1439,38 @@ private:
   // The primal and the dual step length are two independent latency-bound chains (Householder
   // steps, one-lane Newton): they run concurrently, X on the main stream and Y on the stream
   // Cholesky(Q) used earlier in the iteration (Z is free by now and serves as Y's work matrix).
-  void step_lengths()
+  // The smallest eigenvalues land in R_LAMX / R_LAMY (a rank without blocks contributes +huge).
+  void queue_step_lengths()
   {
-    {
-      Timer t(this, "stepLength(XCholesky)"); // both chains; the reductions are timed under the Y name
-      if(Jl_)
+    Timer t(this, "stepLength");
+    if(Jl_)
+      {
+        HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
+        HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
+        enqueue_min_eigenvalues(Xc_, LiX_, dX_, W_, eigD_, eigE_, eigF_, lam_);
         {
-          HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
-          HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
-          enqueue_min_eigenvalues(Xc_, LiX_, dX_, W_, eigD_, eigE_, eigF_, lam_);
-          std::swap(stream_, stream_q_);
+          OnSideStream side(this);
           enqueue_min_eigenvalues(Yc_, LiY_, dY_, Z_, eigD2_, eigE2_, eigF2_, lam2_);
           HIP_CHECK(hipEventRecord(ev_q_done_, stream_));
-          std::swap(stream_, stream_q_);
-          HIP_CHECK(hipStreamWaitEvent(stream_, ev_q_done_, 0));
         }
-    }
-    Timer t(this, "stepLength(YCholesky)");
-    primal_step_length_ = step_length_from(lam_);
-    dual_step_length_ = step_length_from(lam2_);
-  }
-  M step_length_from(const DevArray &lam)
-  {
-    mw::CPtr lp = lam.cptr();
-    M lambda = reduce<RED_MIN>((size_t)2 * Jl_, [=] __device__(size_t i) { return mw::load<NL>(lp, i); });
-    if(Jl_ == 0)
-      {
-        lambda = mw::from_u32<NL>(1);
-        lambda.e = 1 << 28;
+        HIP_CHECK(hipStreamWaitEvent(stream_, ev_q_done_, 0));
       }
-    lambda = allreduce_scalar(lambda, RED_MIN);
+    M huge = mw::from_u32<NL>(1);
+    huge.e = 1 << 28;
+    mw::CPtr lp = lam_.cptr(), lp2 = lam2_.cptr();
+    reduce_to<RED_MIN>(R_LAMX, (size_t)2 * Jl_, [=] __device__(size_t i) { return mw::load<NL>(lp, i); }, huge);
+    reduce_to<RED_MIN>(R_LAMY, (size_t)2 * Jl_, [=] __device__(size_t i) { return mw::load<NL>(lp2, i); }, huge);
+  }
+  M step_length_from(const M &lambda)
+  {
     const M &gamma = step_length_reduction_;
     if(mw::gt(lambda, mw::neg(gamma)))
       return mw::from_u32<NL>(1);
     return mw::div(mw::neg(gamma), lambda);
   }
 
-  // update_cond_numbers.hxx:16-110
-  void update_cond_numbers()
+  // update_cond_numbers.hxx:16-110: the ratios and the winner are found on the device
+  void queue_cond_numbers()
   {
     Timer t(this, "condition_numbers");
     const int J1 = std::max(Jl_, 1);
@@ -1319,125 +1480,102 @@ private:
         launch(k_diag_ratio<NL>, dim3(2 * Jl_), dim3(DR_T), stream_, psd(Xc_), ratio_.ptr(), (size_t)J1);
         launch(k_diag_ratio<NL>, dim3(2 * Jl_), dim3(DR_T), stream_, psd(Yc_), ratio_.ptr(), (size_t)3 * J1);
       }
-    launch(k_diag_ratio<NL>, dim3(1), dim3(DR_T), stream_, QB(), ratio_.ptr(), (size_t)5 * J1);
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    std::vector<M> r = download<NL>(ratio_, 0, (size_t)5 * J1 + 1);
-    Q_cond_number_ = mw::mul(r[5 * J1], r[5 * J1]);
-    // candidates in the reference's scan order (block, then parity: S, X, Y)
-    M best = mw::zero<NL>();
-    int best_global = -1, best_kind = 0, best_parity = 0;
-    for(int l = 0; l < Jl_; ++l)
-      {
-        auto consider = [&](const M &v, int kind, int parity) {
-          const int g = local_[l];
-          const bool better = mw::lt(best, v) || (mw::cmp(best, v) == 0 && best_global >= 0 && g < best_global);
-          if(better && !mw::is_zero(v))
-            {
-              best = v;
-              best_global = g;
-              best_kind = kind;
-              best_parity = parity;
-            }
-        };
-        consider(r[l], 0, 0);
-        for(int b = 0; b < 2; ++b)
-          {
-            consider(r[J1 + 2 * l + b], 1, b);
-            consider(r[3 * J1 + 2 * l + b], 2, b);
-          }
-      }
-    if(world_ > 1)
-      {
-        // every rank proposes (value, global block, kind, parity); winner = max value
-        M tag = mw::from_u32<NL>((uint32_t)std::max(best_global, 0) * 8u + (uint32_t)best_kind * 2u + (uint32_t)best_parity + 1u);
-        std::vector<M> all = allgather(std::vector<M>{best, tag});
-        int w = 0;
-        for(int k = 1; k < world_; ++k)
-          if(mw::lt(all[2 * w], all[2 * k]))
-            w = k;
-        best = all[2 * w];
-        const uint32_t code = (uint32_t)mw::to_double(all[2 * w + 1]) - 1u;
-        best_global = (int)(code / 8u);
-        best_kind = (int)((code % 8u) / 2u);
-        best_parity = (int)(code % 2u);
-      }
-    max_block_cond_number_ = mw::mul(best, best);
+    launch(k_diag_ratio<NL>, dim3(1), dim3(DR_T), stream_, QB(), res(), (size_t)R_QCOND);
+    launch(k_cond_best<NL>, dim3(1), dim3(WG), stream_, ratio_.cptr(), Jl_, (const BlockDesc *)d_blk_.p, res(), (size_t)R_COND, xwords() + XW_TAG);
+  }
+  void finish_cond_numbers()
+  {
+    Q_cond_number_ = mw::mul(res_host_[R_QCOND], res_host_[R_QCOND]);
+    max_block_cond_number_ = mw::mul(res_host_[R_COND], res_host_[R_COND]);
+    const uint32_t tag = xw_host_[XW_TAG];
     std::ostringstream ss;
-    if(best_kind == 0)
-      ss << "schur_complement_cholesky.block_" << best_global;
+    if(tag)
+      {
+        const uint32_t code = tag - 1u;
+        const int g = (int)(code / 8u), kind = (int)((code % 8u) / 2u), parity = (int)(code % 2u);
+        if(kind == 0)
+          ss << "schur_complement_cholesky.block_" << g;
+        else
+          ss << (kind == 1 ? "X" : "Y") << "_cholesky.block_" << g << "_" << parity;
+      }
     else
-      ss << (best_kind == 1 ? "X" : "Y") << "_cholesky.block_" << best_global << "_" << best_parity;
+      ss << "schur_complement_cholesky.block_-1";
     max_block_cond_number_name_ = ss.str();
   }
 
-  // step.cxx:51-229; returns true when mu > maxComplementarity
-  bool step(bool feasible)
+  // -XY and its trace (scale_multiply_add.cxx:4-13, step.cxx:137-144); only X and Y enter, so
+  // it is queued with the residues and mu reaches the host at the first synchronisation point
+  void queue_minus_XY_and_trace()
   {
+    Timer t(this, "XY");
+    gemm_psd(X_, Y_, mXY_, true, false);
+    const MatDesc *dv = d_vecn_.p, *dp = d_psd_.p;
+    mw::CPtr a = mXY_.cptr();
+    const int nq = 2 * Jl_;
+    reduce_to<RED_SUM>(R_TRACE, psd_rows_local_, [=] __device__(size_t i) {
+      int q = 0;
+      while(q + 1 < nq && dv[q + 1].off <= i)
+        ++q;
+      const int r = (int)(i - dv[q].off);
+      return mw::load<NL>(a, (size_t)dp[q].off + (size_t)r * (dp[q].ld + 1));
+    });
+  }
+  // compute_R_error.hxx:9-29 : max |(-XY) + mu I| into R_RERR (mu is scal_[S_MU])
+  void queue_R_error()
+  {
+    Timer t(this, "R_error");
+    const MatDesc *dp = d_psd_.p;
+    mw::CPtr a = mXY_.cptr(), sc = scal_.cptr();
+    const int nq = 2 * Jl_;
+    reduce_to<RED_MAX>(R_RERR, psd_elems_, [=] __device__(size_t i) {
+      int q = 0;
+      while(q + 1 < nq && dp[q + 1].off <= i)
+        ++q;
+      const size_t e = i - (size_t)dp[q].off;
+      const int n = dp[q].rows;
+      M v = mw::load<NL>(a, i);
+      if(e % n == e / n)
+        v = mw::add(v, mw::load<NL>(sc, S_MU));
+      return mw::abs(v);
+    });
+  }
+
+  // step.cxx:51-229 (mu and the termination tests were settled by iterate())
+  void step(bool feasible)
+  {
+    upload_scalar(S_MU, mu_);
+    queue_R_error();
     initialize_schur_complement_solver();
-    {
-      Timer t(this, "XY");
-      gemm_psd(X_, Y_, mXY_, true, false);
-    }
-    {
-      Timer t(this, "mu");
-      // trace: one lane per diagonal element
-      const MatDesc *dv = d_vecn_.p, *dp = d_psd_.p;
-      mw::CPtr a = mXY_.cptr();
-      const int nq = 2 * Jl_;
-      M tr = reduce<RED_SUM>(psd_rows_local_, [=] __device__(size_t i) {
-        int q = 0;
-        while(q + 1 < nq && dv[q + 1].off <= i)
-          ++q;
-        const int r = (int)(i - dv[q].off);
-        return mw::load<NL>(a, (size_t)dp[q].off + (size_t)r * (dp[q].ld + 1));
-      });
-      tr = allreduce_scalar(tr, RED_SUM);
-      mu_ = mw::div(mw::neg(tr), mw::from_u32<NL>((uint32_t)total_psd_rows_));
-    }
-    if(mw::gt(mu_, max_complementarity_))
-      {
-        join_cholesky_Q();
-        return true;
-      }
-    {
-      // compute_R_error.hxx:9-29 : max |(-XY) + mu I|
-      Timer t(this, "R_error");
-      upload_scalar(S_MU, mu_);
-      const MatDesc *dp = d_psd_.p;
-      mw::CPtr a = mXY_.cptr(), sc = scal_.cptr();
-      const int nq = 2 * Jl_;
-      M re = reduce<RED_MAX>(psd_elems_, [=] __device__(size_t i) {
-        int q = 0;
-        while(q + 1 < nq && dp[q + 1].off <= i)
-          ++q;
-        const size_t e = i - (size_t)dp[q].off;
-        const int n = dp[q].rows;
-        M v = mw::load<NL>(a, i);
-        if(e % n == e / n)
-          v = mw::add(v, mw::load<NL>(sc, S_MU));
-        return mw::abs(v);
-      });
-      R_error_ = allreduce_scalar(re, RED_MAX);
-    }
     {
       Timer t(this, "computeSearchDirection(betaPredictor)");
       const M beta_predictor = feasible ? mw::zero<NL>() : infeasible_centering_parameter_; // predictor_centering_parameter.cxx:4-9
       compute_search_direction(beta_predictor, false);
     }
+    // ---- synchronisation point 2: the corrector's centering parameter needs sum (X+dX).(Y+dY)
+    queue_frobenius_product();
+    exchange({{R_FROB, X_SUM}, {R_RERR, X_MAX}});
+    fetch(); // raises Cholesky failures of S_j and Q
+    R_error_ = res_host_[R_RERR];
     {
       Timer t(this, "computeSearchDirection(betaCorrector)");
       beta_corrector_ = corrector_centering_parameter(feasible);
       compute_search_direction(beta_corrector_, true);
     }
-    update_cond_numbers();
-    step_lengths();
+    queue_cond_numbers();
+    queue_step_lengths();
+    // ---- synchronisation point 3: step lengths (and the condition numbers for the log)
+    exchange({{R_LAMX, X_MIN}, {R_LAMY, X_MIN}, {R_COND, X_ARGMAX}});
+    fetch();
+    finish_cond_numbers();
+    primal_step_length_ = step_length_from(res_host_[R_LAMX]);
+    dual_step_length_ = step_length_from(res_host_[R_LAMY]);
     if(feasible)
       {
         primal_step_length_ = mw::min(primal_step_length_, dual_step_length_);
         dual_step_length_ = primal_step_length_;
       }
     {
-      // step.cxx:208-224
+      // step.cxx:208-224; queued, not waited for: the next synchronisation point covers it
       Timer t(this, "update");
       upload_scalar(S_ALPHA_P, primal_step_length_);
       upload_scalar(S_ALPHA_D, dual_step_length_);
@@ -1446,7 +1584,6 @@ private:
       axpy_scalar(S_ALPHA_D, dy_, y_, (size_t)N_);
       axpy_scalar(S_ALPHA_D, dY_, Y_, psd_elems_);
     }
-    return false;
   }
   void axpy_scalar(int slot, const DevArray &d, DevArray &v, size_t count)
   {
@@ -1458,25 +1595,56 @@ private:
   }
 
 public:
-  // One pass of run.cxx:322-467.  Returns true when the loop terminates.
+  // One pass of run.cxx:322-467.  Returns true when the loop terminates.  Three host
+  // synchronisation points (fetch()): the termination test, the corrector's centering parameter,
+  // the step lengths; everything else is queued ahead of the GPU.
   bool iterate() override
   {
+    if(!started_)
+      {
+        started_ = true;
+        start_time_ = std::chrono::steady_clock::now();
+      }
     iteration_ += 1;
-    compute_objectives();
+    {
+      // failure tag, rank 0's wall-clock verdict, SIGTERM seen on this rank
+      const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start_time_).count();
+      launch(k_store_words4<0>, dim3(1), dim3(64), stream_, xwords(), 0xffffffffu, elapsed >= max_runtime_s_ ? 1u : 0u,
+             stop_requested_.load() ? 1u : 0u, 0u);
+    }
+    // ---- synchronisation point 1: everything the termination test needs (run.cxx:380-435) and mu
+    queue_objectives();
     factor_X_and_Y();
     compute_bilinear_pairings();
     compute_dual_residues_and_error();
     compute_primal_residues_P();
     compute_primal_residue_p();
+    queue_minus_XY_and_trace();
+    exchange({{R_CX, X_SUM}, {R_DERR, X_MAX}, {R_PERR_P, X_MAX}, {R_TRACE, X_SUM}});
+    fetch(); // raises Cholesky failures of X and Y
+    if(xw_host_[XW_OR])
+      {
+        terminate_reason_ = SIGTERM_Received; // run.cxx:332-355: any rank, graceful exit
+        return true;
+      }
+    primal_objective_ = mw::add(objective_const_, res_host_[R_CX]);
+    dual_objective_ = mw::add(objective_const_, res_host_[R_BY]);
+    const M denom = mw::max(mw::add(mw::abs(primal_objective_), mw::abs(dual_objective_)), mw::from_u32<NL>(1));
+    duality_gap_ = mw::div(mw::abs(mw::sub(primal_objective_, dual_objective_)), denom);
+    dual_error_ = res_host_[R_DERR];
+    primal_error_P_ = res_host_[R_PERR_P];
+    primal_error_p_ = res_host_[R_PERR_p];
     bool feasible = false;
-    if(compute_feasible_and_termination(feasible))
+    if(compute_feasible_and_termination(feasible, xw_host_[XW_STOP] != 0))
       return true;
     Timer t(this, "step");
-    if(step(feasible))
+    mu_ = mw::div(mw::neg(res_host_[R_TRACE]), mw::from_u32<NL>((uint32_t)total_psd_rows_));
+    if(mw::gt(mu_, max_complementarity_)) // step.cxx:145-153
       {
         terminate_reason_ = MaxComplementarityExceeded;
         return true;
       }
+    step(feasible);
     return false;
   }
 
@@ -1566,6 +1734,32 @@ public:
         out += "\n";
       }
     return out;
+  }
+  // binary flavours: column-major mpf_t-layout records (exact when limbs64 >= NL/2 + 1)
+  size_t get_array_mpf(const std::string &which, int j, int parity, int limbs64, uint64_t *out, size_t capacity) override
+  {
+    const ArrayRef r = locate(which, j, parity);
+    if(!out || capacity < r.count)
+      return r.count;
+    if(limbs64 < 1)
+      throw SolverError(4, "get_array_mpf: limbs64 < 1");
+    join_cholesky_Q();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const std::vector<M> v = download<NL>(*r.a, r.off, r.count);
+    for(size_t i = 0; i < v.size(); ++i)
+      mw::to_mpf_record<NL>(v[i], out + i * (size_t)(limbs64 + 2), limbs64);
+    return r.count;
+  }
+  void set_array_mpf(const std::string &which, int j, int parity, int limbs64, const uint64_t *values, size_t count) override
+  {
+    if(which != "x" && which != "X" && which != "y" && which != "Y")
+      throw SolverError(4, "set_array: only x, X, y, Y can be set");
+    if(which != "y" && local_index(j) < 0)
+      return;
+    const ArrayRef r = locate(which, j, parity);
+    if(count != r.count)
+      throw SolverError(4, "set_array_mpf: wrong element count for " + which);
+    upload<NL>(*r.a, r.off, records(values, count, limbs64));
   }
   // checkpoint-style state injection (x, X, y, Y): column-major decimals
   void set_array(const std::string &which, int j, int parity, const char *txt) override

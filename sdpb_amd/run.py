@@ -151,6 +151,17 @@ def solve(argv: Optional[List[str]] = None) -> str:
     solver = SDPSolver(sdp, o.precision, params, device=o.device, lib_path=o.lib)
     if o.initialCheckpointDir:
         load_text_checkpoint(solver, sdp, o.initialCheckpointDir)
+    # --maxRuntime is tested inside the iteration, where the reference tests it
+    # (compute_feasible_and_termination.cxx:51-56), against the time left of the budget
+    if o.maxRuntime < float("inf"):
+        solver.set_max_runtime(max(0.0, o.maxRuntime - (time.time() - start)))
+    # SIGTERM: finish gracefully at the next iteration boundary (run.cxx:332-355, Environment.cxx:58-59)
+    import signal
+    previous_handler = None
+    try:
+        previous_handler = signal.signal(signal.SIGTERM, lambda *_: solver.request_stop())
+    except ValueError:  # not the main thread (tests): the caller may still use solver.request_stop()
+        pass
     if o.verbosity >= 1:
         print(f"Initialize SDP solver\n\tprimal dimension: {sdp.P_total}\n\tdual dimension: {sdp.N}"
               f"\n\tSDP blocks: {sdp.J}")
@@ -175,9 +186,9 @@ def solve(argv: Optional[List[str]] = None) -> str:
                 print(f"{solver.iteration:<4d}  {int(now - start):>8d} {f('mu'):<8.2g} {f('P-obj'):<+11.3g} "
                       f"{f('D-obj'):<+11.3g} {f('gap'):<10.3g} {f('P-err'):<+11.3g} {f('p-err'):<+11.3g} "
                       f"{f('D-err'):<+11.3g} {f('P-step'):<8.3g} {f('D-step'):<8.3g} {f('beta'):<4.3g}", flush=True)
-            if now - start >= o.maxRuntime:
-                reason = "maxRuntime exceeded"
         itf.write("\n]")
+    if previous_handler is not None:
+        signal.signal(signal.SIGTERM, previous_handler)
     runtime = int(time.time() - start)
     out = solver.out_txt()
     out["terminateReason"] = reason

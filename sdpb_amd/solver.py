@@ -46,6 +46,7 @@ class SDPBError(RuntimeError):
         self.code = code
 
 
+RCCL_ID_BYTES = 128  # SDPB_HIP_RCCL_ID_BYTES
 _libs: Dict[str, ctypes.CDLL] = {}
 
 
@@ -90,6 +91,13 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_get_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_char_p, ctypes.c_size_t, size_p]
     L.sdpb_hip_set_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    ull_p_ = ctypes.POINTER(ctypes.c_ulonglong)
+    L.sdpb_hip_set_block_mpf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ull_p_, ull_p_, ull_p_, ull_p_]
+    L.sdpb_hip_set_objective_mpf.argtypes = [ctypes.c_void_p, ctypes.c_int, ull_p_, ull_p_]
+    L.sdpb_hip_get_array_mpf.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ull_p_,
+                                         ctypes.c_size_t, size_p]
+    L.sdpb_hip_set_array_mpf.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ull_p_,
+                                         ctypes.c_size_t]
     L.sdpb_hip_block_owner.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sdpb_hip_limbs.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_fx_frac_bits.argtypes = [ctypes.c_void_p]
@@ -97,6 +105,16 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                                     ctypes.POINTER(ctypes.c_double)]
     L.sdpb_hip_set_collectives.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Collectives)]
     L.sdpb_hip_timers.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, size_p]
+    L.sdpb_hip_rccl_unique_id.argtypes = [ctypes.c_char_p]
+    L.sdpb_hip_rccl_init.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.sdpb_hip_comm_name.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_comm_name.restype = ctypes.c_char_p
+    L.sdpb_hip_set_max_runtime.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    L.sdpb_hip_request_stop.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_request_stop.restype = None
+    L.sdpb_hip_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sdpb_hip_host_syncs.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_host_syncs.restype = ctypes.c_long
     L.sdpb_hip_plan_blocks.argtypes = [ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int, c_int_p]
     L.sdpb_hip_op_scalar.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 4 + [ctypes.c_size_t, size_p]
     L.sdpb_hip_op_int_syrk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
@@ -206,6 +224,37 @@ class SDPSolver:
         self._cb_keepalive = cb
         self._chk(self.L.sdpb_hip_set_collectives(self.h, ctypes.byref(cb)))
 
+    def rccl_unique_id(self) -> bytes:
+        """Rank 0: the id every rank passes to rccl_init (distribute it by any means)."""
+        buf = ctypes.create_string_buffer(RCCL_ID_BYTES)
+        rc = self.L.sdpb_hip_rccl_unique_id(buf)
+        if rc:
+            raise SDPBError(rc, self.L.sdpb_hip_last_error(None).decode())
+        return buf.raw
+
+    def rccl_init(self, unique_id: bytes):
+        """Collective over all ranks: the exchange runs on RCCL inside the library from now on."""
+        assert len(unique_id) == RCCL_ID_BYTES
+        self._chk(self.L.sdpb_hip_rccl_init(self.h, ctypes.create_string_buffer(unique_id, RCCL_ID_BYTES)))
+
+    @property
+    def comm_name(self) -> str:
+        return self.L.sdpb_hip_comm_name(self.h).decode()
+
+    def set_max_runtime(self, seconds: float):
+        self._chk(self.L.sdpb_hip_set_max_runtime(self.h, float(seconds)))
+
+    def request_stop(self):
+        """Graceful stop at the next iteration boundary (SIGTERM semantics of run.cxx:332-355)."""
+        self.L.sdpb_hip_request_stop(self.h)
+
+    def set_profiling(self, on: bool):
+        self._chk(self.L.sdpb_hip_set_profiling(self.h, int(bool(on))))
+
+    @property
+    def host_syncs(self) -> int:
+        return int(self.L.sdpb_hip_host_syncs(self.h))
+
     # -- SDP_Solver surface -------------------------------------------------------
     def block_owner(self, j: int) -> int:
         return self.L.sdpb_hip_block_owner(self.h, j)
@@ -244,6 +293,37 @@ class SDPSolver:
     def array(self, which: str, j: int = 0, parity: int = 0) -> List[str]:
         return self._string(self.L.sdpb_hip_get_array, which.encode(), j, parity).split()
 
+    # -- binary number path: numpy uint64 arrays of mpf_t-layout records, shape (count, 2 + limbs64) --
+    @staticmethod
+    def _rec(a):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), a.shape[-1] - 2
+
+    def set_block_mpf(self, j: int, bases_even, bases_odd, B, c):
+        (e, pe, l1), (o, po, l2), (b, pb, l3), (cc, pc, l4) = map(self._rec, (bases_even, bases_odd, B, c))
+        assert l1 == l2 == l3 == l4
+        self._chk(self.L.sdpb_hip_set_block_mpf(self.h, j, l1, pe, po, pb, pc))
+
+    def set_objective_mpf(self, b, constant):
+        (bb, pb, l1), (cc, pc, l2) = self._rec(b), self._rec(constant)
+        assert l1 == l2
+        self._chk(self.L.sdpb_hip_set_objective_mpf(self.h, l1, pb, pc))
+
+    def array_mpf(self, which: str, j: int = 0, parity: int = 0, limbs64: Optional[int] = None):
+        import numpy as np
+        limbs64 = limbs64 or self.limbs // 2 + 1
+        n = ctypes.c_size_t(0)
+        self._chk(self.L.sdpb_hip_get_array_mpf(self.h, which.encode(), j, parity, limbs64, None, 0, ctypes.byref(n)))
+        out = np.zeros((n.value, 2 + limbs64), dtype=np.uint64)
+        self._chk(self.L.sdpb_hip_get_array_mpf(self.h, which.encode(), j, parity, limbs64,
+                                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), n.value, ctypes.byref(n)))
+        return out
+
+    def set_array_mpf(self, which: str, values, j: int = 0, parity: int = 0):
+        v, pv, l = self._rec(values)
+        self._chk(self.L.sdpb_hip_set_array_mpf(self.h, which.encode(), j, parity, l, pv, v.shape[0]))
+
     def set_array(self, which: str, values: List[str], j: int = 0, parity: int = 0):
         self._chk(self.L.sdpb_hip_set_array(self.h, which.encode(), j, parity, " ".join(values).encode()))
 
@@ -255,16 +335,16 @@ class SDPSolver:
         return json.loads(self._string(self.L.sdpb_hip_timers))
 
     def run(self, max_runtime: float = float("inf"), on_iteration: Optional[Callable] = None) -> str:
-        """SDP_Solver::run: iterate until a terminate reason is set; returns it."""
-        start = time.time()
+        """SDP_Solver::run: iterate until a terminate reason is set; returns it.  max_runtime is
+        tested inside the iteration (compute_feasible_and_termination.cxx:51-56)."""
+        if max_runtime < float("inf"):
+            self.set_max_runtime(max_runtime)
         while True:
             if self.iterate():
                 return self.terminate_reason
             rec = {"iteration": self.iteration, **self.scalars()}
             if on_iteration:
                 on_iteration(rec)
-            if time.time() - start >= max_runtime:
-                return "maxRuntime exceeded"
 
     def out_txt(self) -> dict:
         """The keys of out.txt (src/sdpb/save_solution.cxx:32-37)."""

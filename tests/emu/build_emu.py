@@ -19,7 +19,7 @@ LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
 LIMBS = (6, 18, 24, 26)
 CXX = os.environ.get("CXX", "g++")
 FLAGS = ["-O1", "-std=c++17", "-fPIC", "-fopenmp", "-x", "c++", "-I" + os.path.join(HERE, "include"),
-         "-Wno-unknown-pragmas", "-Wno-attributes"]
+         "-Wno-unknown-pragmas", "-Wno-attributes", "-DSDPB_NO_RCCL"]
 
 
 def _digest(deps):

@@ -191,6 +191,13 @@ inline int atomicMax(int *p, int v)
     {}
   return old;
 }
+inline unsigned atomicMin(unsigned *p, unsigned v)
+{
+  unsigned old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while(old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST))
+    ;
+  return old;
+}
 inline int atomicMin(int *p, int v)
 {
   int old = __atomic_load_n(p, __ATOMIC_SEQ_CST);

@@ -204,3 +204,23 @@ def test_Y_cholesky_failure_names_block_and_parity():
     assert e.value.code == 1
     assert "Block_Diagonal_Matrix Y, block index = 1, parity = 1" in str(e.value)
     s.close()
+
+
+def test_rccl_binding_inside_the_library():
+    """The in-library exchange (csrc/rccl_comm.hpp) links and drives RCCL on the library's stream:
+    one-rank communicator, all-gather + 64-bit SUM all-reduce through the solver's Comm class."""
+    import ctypes
+    from sdpb_amd.solver import load_library
+    L = load_library(libs.product_lib())
+    L.sdpb_hip_rccl_selftest.argtypes = [ctypes.c_size_t]
+    rc = L.sdpb_hip_rccl_selftest(1 << 20)
+    assert rc == 0, L.sdpb_hip_last_error(None).decode()
+
+
+def test_three_host_synchronisation_points_per_iteration_on_the_device():
+    c = _shape("C3", 0.1)
+    sdp, s, _ = _pair(c, oracle=False)
+    for _ in range(3):
+        assert not s.iterate()
+    assert s.host_syncs == 9
+    s.close()

@@ -1,0 +1,122 @@
+"""Host logic of the iteration driver on the CPU emulation build: the three synchronisation
+points, --maxRuntime inside the termination test, graceful stop, and errors that every rank
+raises identically.  (The gfx950 library runs the same host code; see tests/test_gpu_parity*.py.)"""
+import os
+import sys
+
+import pytest
+
+from sdpb_amd.solver import SDPBError, SDPSolver
+from tests import libs, parity
+
+
+def _solver(name="1d-constraints", **kw):
+    sdp, meta, iters, out = parity.load_case(name)
+    return sdp, SDPSolver(sdp, meta["precision"], meta["params"], lib_path=libs.emu_lib(), **kw), iters
+
+
+def test_three_host_synchronisation_points_per_iteration():
+    _, s, _ = _solver()
+    for _ in range(4):
+        assert not s.iterate()
+    assert s.host_syncs == 3 * 4
+    s.close()
+
+
+def test_max_runtime_is_tested_inside_the_iteration_before_the_step():
+    """compute_feasible_and_termination.cxx:51-56: the state the run ends with is the one the
+    objectives in out.txt were computed from (no step after the test)."""
+    _, s, _ = _solver()
+    for _ in range(2):
+        assert not s.iterate()
+    x_before = s.array("x", 0)
+    s.set_max_runtime(0.0)
+    assert s.iterate()
+    assert s.terminate_reason == "maxRuntime exceeded"
+    assert s.array("x", 0) == x_before
+    s.close()
+
+
+def test_max_iterations_takes_precedence_over_max_runtime():
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, meta["precision"], dict(meta["params"], maxIterations=2), lib_path=libs.emu_lib())
+    s.set_max_runtime(0.0)
+    s.set_max_runtime(1e9)
+    assert not s.iterate() and not s.iterate()
+    s.set_max_runtime(0.0)
+    assert s.iterate()
+    assert s.terminate_reason == "maxIterations exceeded"
+    s.close()
+
+
+def test_request_stop_ends_the_run_gracefully_with_the_sigterm_reason():
+    _, s, _ = _solver()
+    assert not s.iterate()
+    y_before = s.array("y")
+    s.request_stop()
+    assert s.iterate()
+    assert s.terminate_reason == "SIGTERM signal received"
+    assert s.array("y") == y_before
+    s.close()
+
+
+def test_profiling_timers_are_off_by_default_and_named_like_the_reference():
+    _, s, _ = _solver()
+    assert not s.iterate()
+    t = s.timers()
+    assert "initializeSchurComplementSolver.Q.syrk" not in t and t["host_syncs"] == 3
+    s.set_profiling(True)
+    assert not s.iterate()
+    t = s.timers()
+    for k in ("choleskyDecomposition", "initializeSchurComplementSolver.Q.syrk", "computeSearchDirection(betaCorrector)",
+              "stepLength"):
+        assert k in t, k
+    s.close()
+
+
+def _failing_rank_worker(rank, world, port, lib, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, libs.ROOT)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sdpb_amd.distributed import make_collectives
+        sdp, meta, _, _ = parity.load_case("1d-constraints")
+        s = SDPSolver(sdp, meta["precision"], meta["params"], rank=rank, world_size=world, lib_path=lib)
+        s.set_collectives(*make_collectives(torch.device("cpu")))
+        assert not s.iterate()
+        # make Y of block 1 indefinite on its owner only: the OTHER rank must raise the same error
+        # instead of running on into the next collective
+        owner = s.block_owner(1)
+        if owner == rank:
+            n = len(s.array("Y", 1, 1))
+            s.set_array("Y", ["-1"] + ["0"] * (n - 1), 1, 1)
+        try:
+            s.iterate()
+            q.put((rank, owner, None))
+        except SDPBError as e:
+            q.put((rank, owner, (e.code, str(e))))
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_cholesky_failure_on_one_rank_is_raised_by_every_rank():
+    import torch.multiprocessing as mp
+    from tests.test_multirank import _free_port
+    lib = libs.emu_lib()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, 2, port, lib, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, _, e0), (_, _, e1) = results
+    assert e0 is not None and e0 == e1, (e0, e1)
+    assert e0[0] == 1 and "Block_Diagonal_Matrix Y, block index = 1, parity = 1" in e0[1]
