@@ -98,6 +98,18 @@ int sdpb_hip_get_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, 
 /* Inject x, X, y or Y (text checkpoint: load_text_checkpoint.cxx:6-44). */
 int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, const char *values);
 
+/* The part of the step that approx_objective and outer_limits reuse
+ * (approx_objective/setup_solver.cxx:204-220, outer_limits/compute_optimal/compute_optimal.cxx:188-215):
+ * from the CURRENT X and Y (e.g. loaded with sdpb_hip_set_array from a text checkpoint) build
+ *   schur_complement_cholesky  L_j = chol(S_j)       -> sdpb_hip_get_array("L", j)
+ *   schur_off_diagonal         P_j = L_j^{-1} B_j    -> sdpb_hip_get_array("PT", j)  (transposed, N x P_j)
+ *   Cholesky(Q)                                      -> sdpb_hip_get_array("Q")      (lower factor)
+ * without modifying x, X, y, Y; same errors as sdpb_hip_iterate.  sdpb_hip_schur_solve then solves
+ * the Schur complement equation (solve_schur_complement_equation.cxx:16-79) for right-hand sides
+ * placed with sdpb_hip_set_array("dx", j) / ("dy"); the solution replaces them. */
+int sdpb_hip_schur_solver_init(sdpb_hip_ctx *ctx);
+int sdpb_hip_schur_solve(sdpb_hip_ctx *ctx);
+
 /* ---- binary number path -------------------------------------------------------
  * The same entry points with every number as a fixed-width record in GMP's mpf_t layout, so
  * a C++ caller holding El::BigFloat (= mpf_t, fmpz_BigFloat_convert.hxx:9,13) never formats

@@ -186,6 +186,14 @@ int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, 
 {
   return guarded(ctx, [&] { ctx->solver->set_array(which, j, parity, values); });
 }
+int sdpb_hip_schur_solver_init(sdpb_hip_ctx *ctx)
+{
+  return guarded(ctx, [&] { ctx->solver->schur_solver_init(); });
+}
+int sdpb_hip_schur_solve(sdpb_hip_ctx *ctx)
+{
+  return guarded(ctx, [&] { ctx->solver->schur_solve(); });
+}
 int sdpb_hip_set_block_mpf(sdpb_hip_ctx *ctx, int j, int limbs64, const unsigned long long *be, const unsigned long long *bo,
                            const unsigned long long *B, const unsigned long long *c)
 {

@@ -4,6 +4,7 @@
 // converts at the C-ABI boundary.  Conversion is exact-then-truncated, computed
 // with a small arbitrary-size integer; no GMP dependency.
 #pragma once
+#include <cstring>
 #include "mw.hpp"
 
 #include <cstdlib>
@@ -137,7 +138,7 @@ template <int NL> Mw<NL> from_decimal(const char *s, const char *end = nullptr)
     }
   flush();
   if(!any)
-    throw std::runtime_error(std::string("bad number: '") + std::string(s, end ? end : s + 32) + "'");
+    throw std::runtime_error(std::string("bad number: '") + std::string(s, end ? (size_t)(end - s) : strnlen(s, 32)) + "'");
   if(!at_end() && (*p == 'e' || *p == 'E'))
     {
       ++p;
@@ -146,7 +147,7 @@ template <int NL> Mw<NL> from_decimal(const char *s, const char *end = nullptr)
       p = q;
     }
   if(!at_end())
-    throw std::runtime_error(std::string("trailing characters in number: '") + std::string(s, end ? end : s + 32) + "'");
+    throw std::runtime_error(std::string("trailing characters in number: '") + std::string(s, end ? (size_t)(end - s) : strnlen(s, 32)) + "'");
   D.trim();
   if(D.is_zero())
     return r;

@@ -159,6 +159,8 @@ public:
   virtual void set_array_mpf(const std::string &which, int j, int parity, int limbs64, const uint64_t *values, size_t count) = 0;
   virtual void init_state() = 0;
   virtual bool iterate() = 0;
+  virtual void schur_solver_init() = 0;
+  virtual void schur_solve() = 0;
   virtual int terminate_reason() const = 0;
   virtual std::string get_scalar(const std::string &name) = 0;
   virtual std::string get_array(const std::string &which, int j, int parity) = 0;
@@ -1648,6 +1650,31 @@ public:
     return false;
   }
 
+  // The piece of the step that approx_objective and outer_limits reuse (approx_objective/
+  // setup_solver.cxx:204-220, outer_limits/compute_optimal.cxx:188-215): from the current X and Y,
+  //   L_j = chol(S_j)            -> get_array("L", j)        schur_complement_cholesky
+  //   P_j = L_j^{-1} B_j         -> get_array("PT", j)       schur_off_diagonal (stored transposed, N x P_j)
+  //   chol(Q), Q = sum P_j^T P_j -> get_array("Q")           lower factor = (El::Cholesky UPPER)^T
+  // without touching x, X, y, Y.  Raises the same errors as the iteration.
+  void schur_solver_init() override
+  {
+    launch(k_store_words4<0>, dim3(1), dim3(64), stream_, xwords(), 0xffffffffu, 0u, 0u, 0u);
+    factor_X_and_Y();
+    compute_bilinear_pairings();
+    initialize_schur_complement_solver();
+    join_cholesky_Q();
+    exchange({});
+    fetch();
+  }
+  // solve_schur_complement_equation.cxx:16-79 with that solver: in dx (set_array "dx", per block)
+  // and dy (set_array "dy"), out the solution in the same arrays
+  void schur_solve() override
+  {
+    copy(dy_, rp_);
+    solve_schur_complement_equation();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+
   // ==========================================================================
   // outputs
   // ==========================================================================
@@ -1752,9 +1779,9 @@ public:
   }
   void set_array_mpf(const std::string &which, int j, int parity, int limbs64, const uint64_t *values, size_t count) override
   {
-    if(which != "x" && which != "X" && which != "y" && which != "Y")
-      throw SolverError(4, "set_array: only x, X, y, Y can be set");
-    if(which != "y" && local_index(j) < 0)
+    if(which != "x" && which != "X" && which != "y" && which != "Y" && which != "dx" && which != "dy")
+      throw SolverError(4, "set_array: only x, X, y, Y (state) and dx, dy (right-hand sides of schur_solve) can be set");
+    if(which != "y" && which != "dy" && local_index(j) < 0)
       return;
     const ArrayRef r = locate(which, j, parity);
     if(count != r.count)
@@ -1764,9 +1791,9 @@ public:
   // checkpoint-style state injection (x, X, y, Y): column-major decimals
   void set_array(const std::string &which, int j, int parity, const char *txt) override
   {
-    if(which != "x" && which != "X" && which != "y" && which != "Y")
-      throw SolverError(4, "set_array: only x, X, y, Y can be set");
-    if(which != "y" && local_index(j) < 0)
+    if(which != "x" && which != "X" && which != "y" && which != "Y" && which != "dx" && which != "dy")
+      throw SolverError(4, "set_array: only x, X, y, Y (state) and dx, dy (right-hand sides of schur_solve) can be set");
+    if(which != "y" && which != "dy" && local_index(j) < 0)
       return;
     const ArrayRef r = locate(which, j, parity);
     upload<NL>(*r.a, r.off, parse_list(txt, r.count, which.c_str()));

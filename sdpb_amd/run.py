@@ -141,7 +141,7 @@ def solve(argv: Optional[List[str]] = None) -> str:
     o = _options(argv)
     out_dir = o.outDir or (o.sdpDir.rstrip("/") + "_out")
     os.makedirs(out_dir, exist_ok=True)
-    sdp = read_sdp(o.sdpDir)
+    sdp = read_sdp(o.sdpDir, o.precision)
     params = {k: parse_option_like_sdpb(getattr(o, k)) for k in PARAM_NAMES}
     params.update(maxIterations=o.maxIterations, findPrimalFeasible=int(o.findPrimalFeasible),
                   findDualFeasible=int(o.findDualFeasible),

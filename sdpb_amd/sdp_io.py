@@ -1,4 +1,5 @@
-"""Reader for the SDP directory format consumed by `sdpb -s <sdpDir>` (JSON flavour).
+"""Reader for the SDP directory format consumed by `sdpb -s <sdpDir>`: plain directory or
+zip/tar archive, block data as JSON or Boost-binary (sdp_bin.py).
 
 Mirrors the reference readers so the on-disk input format stays unchanged:
   control.json        -> num_blocks            (src/sdp_solve/Block_Info/read_block_info.cxx:38)
@@ -85,25 +86,59 @@ def block_text(blk: SDPBlock):
             _flat(blk.B).encode(), _flat(blk.c).encode())
 
 
-def read_sdp(path: str) -> SDP:
-    """Read a JSON-format SDP directory written by pmp2sdp --outputFormat=json."""
-    if not os.path.isdir(path):
-        raise FileNotFoundError(f"SDP path does not exist or is not a directory: {path}")
-    with open(os.path.join(path, "control.json")) as f:
-        num_blocks = int(json.load(f)["num_blocks"])
-    with open(os.path.join(path, "objectives.json")) as f:
-        obj = json.load(f)
+class _Source:
+    """An SDP directory or any archive of one (pmp2sdp --zip; the reference reads every libarchive
+    format, src/sdpb_util/Archive_Reader.cxx; here zip, tar, tar.gz/bz2/xz)."""
+
+    def __init__(self, path: str):
+        import tarfile
+        import zipfile
+        self.path = path
+        self.zip = self.tar = None
+        if os.path.isdir(path):
+            self.names = set(os.listdir(path))
+        elif os.path.isfile(path) and zipfile.is_zipfile(path):
+            self.zip = zipfile.ZipFile(path)
+            self.names = {os.path.basename(n): n for n in self.zip.namelist() if not n.endswith("/")}
+        elif os.path.isfile(path) and tarfile.is_tarfile(path):
+            self.tar = tarfile.open(path)
+            self.names = {os.path.basename(m.name): m for m in self.tar.getmembers() if m.isfile()}
+        else:
+            raise FileNotFoundError(f"SDP path does not exist or is neither a directory nor a zip/tar archive: {path}")
+
+    def has(self, name: str) -> bool:
+        return name in self.names
+
+    def read(self, name: str) -> bytes:
+        if name not in self.names:
+            raise FileNotFoundError(f"{os.path.join(self.path, name)} not found")
+        if self.zip:
+            return self.zip.read(self.names[name])
+        if self.tar:
+            return self.tar.extractfile(self.names[name]).read()
+        with open(os.path.join(self.path, name), "rb") as f:
+            return f.read()
+
+
+def read_sdp(path: str, precision: Optional[int] = None) -> SDP:
+    """Read an SDP written by pmp2sdp: a directory or a zip/tar archive of it, block data in the
+    JSON flavour (--outputFormat=json) or the Boost-binary one (the default, sdp_bin.py; needs
+    `precision`, which must be the --precision the SDP was written with, read_block_data: SDP_Block_Data.cxx:41-43)."""
+    src = _Source(path)
+    num_blocks = int(json.loads(src.read("control.json"))["num_blocks"])
+    obj = json.loads(src.read("objectives.json"))
     blocks = []
     for j in range(num_blocks):
-        with open(os.path.join(path, f"block_info_{j}.json")) as f:
-            info = json.load(f)
-        data_path = os.path.join(path, f"block_data_{j}.json")
-        if not os.path.exists(data_path):
-            raise FileNotFoundError(
-                f"{data_path}: only the JSON block_data flavour is read here "
-                "(Boost-binary .bin is listed as a follow-up in DESIGN.md)")
-        with open(data_path) as f:
-            d = json.load(f)
+        info = json.loads(src.read(f"block_info_{j}.json"))
+        if src.has(f"block_data_{j}.json"):
+            d = json.loads(src.read(f"block_data_{j}.json"))
+        elif src.has(f"block_data_{j}.bin"):
+            if precision is None:
+                raise ValueError(f"{path}: block_data_{j}.bin needs the --precision the SDP was written with")
+            from .sdp_bin import read_block_data_bin
+            d = read_block_data_bin(src.read(f"block_data_{j}.bin"), precision)
+        else:
+            raise FileNotFoundError(f"{path}: neither block_data_{j}.json nor block_data_{j}.bin")
         blk = SDPBlock(dim=int(info["dim"]), num_points=int(info["num_points"]),
                        bases_even=d["bilinear_bases_even"], bases_odd=d["bilinear_bases_odd"],
                        B=d["B"], c=d["c"])
@@ -113,16 +148,15 @@ def read_sdp(path: str) -> SDP:
         assert len(blk.c) == blk.schur_size and len(blk.B) == blk.schur_size
         blocks.append(blk)
     norm = None
-    npath = os.path.join(path, "normalization.json")
-    if os.path.exists(npath):
-        with open(npath) as f:
-            norm = json.load(f).get("normalization")
+    if src.has("normalization.json"):
+        norm = json.loads(src.read("normalization.json")).get("normalization")
     return SDP(blocks=blocks, b=list(obj["b"]), constant=str(obj["constant"]),
                normalization=norm, path=path)
 
 
-def write_sdp(sdp: SDP, path: str, command: str = "sdpb_amd synthetic generator") -> None:
-    """Write an SDP in the same JSON directory format (readable by the real sdpb)."""
+def write_sdp(sdp: SDP, path: str, command: str = "sdpb_amd synthetic generator", fmt: str = "json",
+              precision: Optional[int] = None) -> None:
+    """Write an SDP directory readable by the real sdpb: fmt "json" or "bin" (sdp_bin.py, needs precision)."""
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "control.json"), "w") as f:
         json.dump({"num_blocks": sdp.J, "command": command}, f, indent=2)
@@ -131,6 +165,11 @@ def write_sdp(sdp: SDP, path: str, command: str = "sdpb_amd synthetic generator"
     for j, blk in enumerate(sdp.blocks):
         with open(os.path.join(path, f"block_info_{j}.json"), "w") as f:
             json.dump({"dim": blk.dim, "num_points": blk.num_points}, f, indent=2)
-        with open(os.path.join(path, f"block_data_{j}.json"), "w") as f:
-            json.dump({"bilinear_bases_even": blk.bases_even,
-                       "bilinear_bases_odd": blk.bases_odd, "c": blk.c, "B": blk.B}, f)
+        d = {"bilinear_bases_even": blk.bases_even, "bilinear_bases_odd": blk.bases_odd, "c": blk.c, "B": blk.B}
+        if fmt == "bin":
+            from .sdp_bin import write_block_data_bin
+            with open(os.path.join(path, f"block_data_{j}.bin"), "wb") as f:
+                f.write(write_block_data_bin(d, precision))
+        else:
+            with open(os.path.join(path, f"block_data_{j}.json"), "w") as f:
+                json.dump(d, f)

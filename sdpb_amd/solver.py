@@ -84,6 +84,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_set_objective.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
     L.sdpb_hip_init_state.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_iterate.argtypes = [ctypes.c_void_p, c_int_p]
+    L.sdpb_hip_schur_solver_init.argtypes = [ctypes.c_void_p]
+    L.sdpb_hip_schur_solve.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_terminate_reason.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_terminate_string.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_terminate_string.restype = ctypes.c_char_p
@@ -281,6 +283,15 @@ class SDPSolver:
         self._chk(self.L.sdpb_hip_init_state(self.h))
         self.iteration = 0
         self.terminated = False
+
+    def schur_solver_init(self):
+        """schur_complement_cholesky ("L"), schur_off_diagonal ("PT") and Cholesky(Q) ("Q") from the
+        current X, Y — what approx_objective/outer_limits reuse (setup_solver.cxx:204-220)."""
+        self._chk(self.L.sdpb_hip_schur_solver_init(self.h))
+
+    def schur_solve(self):
+        """Solve the Schur complement equation for the right-hand sides in "dx"/"dy" (in place)."""
+        self._chk(self.L.sdpb_hip_schur_solve(self.h))
 
     def scalar(self, name: str) -> str:
         return self._string(self.L.sdpb_hip_get_scalar, name.encode())

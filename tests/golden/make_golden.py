@@ -72,6 +72,9 @@ def main():
             shutil.copy(cmby, os.path.join(dst, "c_minus_By.json"))
         meta[name] = {"precision": prec, "params": params, "source": source,
                       "reference_dir": "test/data/end-to-end_tests/" + sub}
+    # the reference's zip-archived SDP (test/src/integration_tests/main.cxx:23; pmp2sdp --zip output):
+    # fixture for the archive reader (sdpb_amd/sdp_io.py, Archive_Reader.cxx)
+    shutil.copy(os.path.join(os.path.dirname(os.path.dirname(REF)), "data", "sdp.zip"), os.path.join(HERE, "sdp.zip"))
     with open(os.path.join(HERE, "cases.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", len(meta), "cases to", HERE)

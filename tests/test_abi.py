@@ -65,3 +65,24 @@ def test_host_u64_lane_image_roundtrip():
     need = ctypes.c_size_t()
     assert lib.sdpb_hip_host_decode_u64(lanes, planes, buf, len(buf), ctypes.byref(need)) == 0
     assert int(buf.value) == sum(vals)
+
+
+def test_header_is_usable_from_c_and_cxx(tmp_path):
+    """include/sdpb_hip.h is the boundary: a C translation unit and a C++ one that take the address
+    of every declared entry point must compile (gcc -std=c99 / g++ -std=c++11) and link against the
+    product library."""
+    import subprocess
+    syms = declared_symbols()
+    body = "#include \"sdpb_hip.h\"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n  fn p[] = {\n" + \
+        ",\n".join(f"    (fn){s}" for s in syms) + "\n  };\n" \
+        "  printf(\"%d entry points\\n\", (int)(sizeof p / sizeof p[0]));\n  return p[0] == 0;\n}\n"
+    lib = libs.product_lib()
+    libdir, libname = os.path.dirname(lib), os.path.basename(lib)
+    for cc, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "cpp")):
+        src = tmp_path / f"use_header.{ext}"
+        src.write_text(body)
+        exe = tmp_path / f"use_header_{ext}"
+        r = subprocess.run([cc, std, "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), str(src),
+                            "-o", str(exe), "-L" + libdir, "-l:" + libname, "-Wl,-rpath," + libdir,
+                            "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
