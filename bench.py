@@ -89,9 +89,8 @@ def cpu_baseline(cfg_name: str, precision: int, seconds_budget: float = 45.0):
         probe_note = "no sdpb binary on $SDPB_BIN/PATH; "
     from oracle.oracle import Oracle
     cores = os.cpu_count() or 1
-    # ~x0.5 (J=300, N=500) costs ~1/9 of the full iteration: seconds on a many-core host; small hosts
-    # (this build container: 8 cores) fall back to x0.25
-    scale = float(os.environ.get("SDPB_BENCH_CPU_SCALE", "0.5" if cores >= 32 else "0.25"))
+    # x0.25 (J=150, N=250, P_tot=10000): 1/29 of the full iteration by the MAC model, ~10 s of CPU per iteration
+    scale = float(os.environ.get("SDPB_BENCH_CPU_SCALE", "0.25"))
     c = synthetic.config(cfg_name, scale)
     sdp, src = synthetic.make_lazy(c["dims"], c["num_points"], c["N"], precision, c["seed"])
     t_setup = time.time()

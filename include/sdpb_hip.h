@@ -198,6 +198,23 @@ long sdpb_hip_host_syncs(sdpb_hip_ctx *ctx);
  * Scoped_Timer hierarchy below "run.iter_*." (SURVEY.md §5). */
 int sdpb_hip_timers(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed);
 
+/* ---- load balancing from measured block costs (the reference's block_timings file) ----
+ * sdpb_hip_create_with_costs: as sdpb_hip_create, with one non-negative cost per block read from a
+ * block_timings file of an earlier run (Block_Info/read_block_costs.cxx:14-59: <sdpDir>/block_timings or
+ * <checkpointDir>/block_timings, one integer per line); the block -> rank plan is the same
+ * longest-processing-time greedy on those costs instead of the analytic model (NULL = analytic).
+ * sdpb_hip_block_timings: microseconds[num_blocks], per iteration, for the blocks THIS rank owns (0
+ * elsewhere: sum over ranks, write_timing.cxx:34-68 writes rank 0's gathered column).  Blocks run batched on
+ * the GPU, so the measured stage times of the profiled iterations (sdpb_hip_set_profiling) are
+ * apportioned by each stage's operation count — Cholesky(S_j) ~ P_j^3/3, L_j^{-1}B_j ~ P_j^2 N/2, the
+ * block's rows of the Q syrk ~ P_j (compute_Q.cxx:40-53, bigint_syrk/Readme.md:325-342).
+ * The unit is microseconds (a GPU block costs well under the reference's 1 ms resolution); consumers
+ * only use the ratios. */
+int sdpb_hip_create_with_costs(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N,
+                               int device_id, int rank, int world_size, const long long *block_costs, sdpb_hip_ctx **out);
+int sdpb_hip_block_timings(sdpb_hip_ctx *ctx, long long *microseconds);
+int sdpb_hip_plan_blocks_with_costs(int num_blocks, const long long *block_costs, int world_size, int *owners);
+
 /* Block -> rank plan without a context or a GPU (pure host logic). owners[j] out. */
 int sdpb_hip_plan_blocks(int num_blocks, const int *dims, const int *num_points, int N, int world_size, int *owners);
 

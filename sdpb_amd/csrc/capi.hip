@@ -74,8 +74,15 @@ __global__ void __launch_bounds__(256) k_copy16(const Quad *src, Quad *dst, size
 
 extern "C" {
 
+int sdpb_hip_create_with_costs(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
+                               int rank, int world_size, const long long *block_costs, sdpb_hip_ctx **out);
 int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
                     int rank, int world_size, sdpb_hip_ctx **out)
+{
+  return sdpb_hip_create_with_costs(precision_bits, num_blocks, dims, num_points, N, device_id, rank, world_size, nullptr, out);
+}
+int sdpb_hip_create_with_costs(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
+                               int rank, int world_size, const long long *block_costs, sdpb_hip_ctx **out)
 {
   if(!out || !dims || !num_points || num_blocks <= 0 || world_size < 1 || rank < 0 || rank >= world_size)
     return fail(nullptr, 4, "sdpb_hip_create: bad argument");
@@ -91,6 +98,14 @@ int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const i
       for(int j = 0; j < num_blocks; ++j)
         if(d[j] <= 0 || k[j] <= 0)
           return fail(nullptr, 4, "sdpb_hip_create: dim and num_points must be positive");
+      std::vector<long long> costs;
+      if(block_costs)
+        {
+          costs.assign(block_costs, block_costs + num_blocks);
+          for(long long c : costs)
+            if(c < 0)
+              return fail(nullptr, 4, "sdpb_hip_create_with_costs: negative block cost");
+        }
       const int want = mw::limbs_for_precision(precision_bits);
       std::unique_ptr<sdpb_hip_ctx> ctx(new sdpb_hip_ctx);
       sdpb::SolverBase *s = nullptr;
@@ -99,7 +114,7 @@ int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const i
       struct Entry
       {
         int limbs;
-        sdpb::SolverBase *(*make)(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+        sdpb::SolverBase *(*make)(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
       };
       const Entry table[] = {{6, sdpb::make_solver_6},   {10, sdpb::make_solver_10}, {16, sdpb::make_solver_16},
                              {18, sdpb::make_solver_18}, {24, sdpb::make_solver_24}, {26, sdpb::make_solver_26},
@@ -107,7 +122,7 @@ int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const i
       for(const Entry &e : table)
         if(want <= e.limbs && e.make)
           {
-            s = e.make(precision_bits, d, k, N, rank, world_size);
+            s = e.make(precision_bits, d, k, N, rank, world_size, costs);
             break;
           }
       if(!s)
@@ -337,6 +352,24 @@ int sdpb_hip_timers(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed)
   return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
 }
 
+int sdpb_hip_block_timings(sdpb_hip_ctx *ctx, long long *microseconds)
+{
+  return guarded(ctx, [&] {
+    if(!microseconds)
+      throw sdpb::SolverError(4, "sdpb_hip_block_timings: null output");
+    ctx->solver->block_timings(microseconds);
+  });
+}
+int sdpb_hip_plan_blocks_with_costs(int num_blocks, const long long *block_costs, int world_size, int *owners)
+{
+  if(num_blocks <= 0 || !block_costs || !owners || world_size < 1)
+    return 4;
+  const std::vector<int> ones(num_blocks, 1);
+  const std::vector<long long> costs(block_costs, block_costs + num_blocks);
+  const std::vector<int> o = sdpb::plan_block_owners(ones, ones, 1, world_size, costs);
+  std::copy(o.begin(), o.end(), owners);
+  return 0;
+}
 int sdpb_hip_plan_blocks(int num_blocks, const int *dims, const int *num_points, int N, int world_size, int *owners)
 {
   if(num_blocks <= 0 || !dims || !num_points || !owners || world_size < 1)

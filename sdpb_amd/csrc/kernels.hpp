@@ -1004,7 +1004,7 @@ template <int FX> constexpr bool fx_two_level()
 #ifdef SDPB_SYRK_ONE_LEVEL
   return false;
 #else
-  return FX % 4 == 0 && FX <= 24;
+  return FX % 4 == 0 && FX <= 32;
 #endif
 }
 template <int FX> constexpr int fx_planes() { return fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2); }
@@ -1819,9 +1819,6 @@ template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
 // (2 M2 + 2)-limb sum once.  The pieces of the NEXT pass are fetched from HBM/L2 into registers
 // while the MACs run and are written to the other LDS buffer when the pass ends (one barrier
 // per pass).  The nine sums are recombined once per output element after the row loop.
-#ifndef SDPB_SYRK2_UNROLL
-#define SDPB_SYRK2_UNROLL 2 // rows whose LDS reads are in flight together (registers: 2 M2 per row)
-#endif
 #ifndef SDPB_SYRK2_PREFETCH
 #define SDPB_SYRK2_PREFETCH 1
 #endif
@@ -1848,12 +1845,13 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   const int i = ti * 16 + li, j = tj * 16 + lj;
   __shared__ __attribute__((aligned(16))) uint32_t sa[2 * NP * M2];
   __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NP * M2];
-  uint32_t g2[9][A2];
-#pragma unroll
-  for(int g = 0; g < 9; ++g)
-#pragma unroll
-    for(int k = 0; k < A2; ++k)
-      g2[g][k] = 0;
+  // NG of the nine products are accumulated per sweep over the rows: all nine when their sums fit
+  // the register file, else (1024-bit operands: 9 x 18 limbs) the three of one first-level operand
+  // at a time — three sweeps, the same passes in another order, each closed by its second-level
+  // recombination into x[sweep]
+  constexpr int NG = FX >= 32 ? 3 : 9, SWEEPS = 9 / NG;
+  uint32_t g2[NG][A2];
+  uint32_t x[3][A];
   uint32_t va[GL][M2], vb[GL][M2];
   auto fetch = [&](int g, unsigned r0) __attribute__((always_inline)) {
 #pragma unroll
@@ -1886,16 +1884,36 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
         piece_store<M2>(sb + (buf * NP + e) * M2, vb[t]);
       }
   };
-  fetch(0, row_begin);
+  // second level: XX = X0X0 + (XtXt - X0X0 - X1X1) B2 + X1X1 B2^2 for X = first-level operand k
+  auto second_level = [&](int k, int g0) __attribute__((always_inline)) {
+    sub_limbs<A2>(g2[g0 + 2], g2[g0]);
+    sub_limbs<A2>(g2[g0 + 2], g2[g0 + 1]);
+#pragma unroll
+    for(int q = 0; q < A; ++q)
+      x[k][q] = q < A2 ? g2[g0][q < A2 ? q : 0] : 0u;
+    add_shifted<A, A2>(x[k], g2[g0 + 2], 32 * M2 - 1, false);
+    add_shifted<A, A2>(x[k], g2[g0 + 1], 64 * M2 - 2, false);
+  };
+#pragma unroll
+  for(int sweep = 0; sweep < SWEEPS; ++sweep)
+  {
+#pragma unroll
+  for(int g = 0; g < NG; ++g)
+#pragma unroll
+    for(int k = 0; k < A2; ++k)
+      g2[g][k] = 0;
+  if(sweep > 0)
+    __syncthreads(); // every wavefront has left the last pass of the previous sweep
+  fetch(sweep * NG, row_begin);
   store(0);
   __syncthreads();
   int buf = 0;
   for(unsigned r0 = row_begin; r0 < row_end; r0 += RBG)
     {
 #pragma unroll
-      for(int g = 0; g < 9; ++g)
+      for(int g = 0; g < NG; ++g)
         {
-          fetch(g < 8 ? g + 1 : 0, g < 8 ? r0 : r0 + RBG);
+          fetch(sweep * NG + (g < NG - 1 ? g + 1 : 0), g < NG - 1 ? r0 : r0 + RBG);
           uint64_t c[2 * M2 - 1];
           uint32_t h[2 * M2 - 1];
 #pragma unroll
@@ -1905,53 +1923,52 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
               h[k] = 0;
             }
           const uint32_t *pa = sa + (buf * NP + li) * M2, *pb = sb + (buf * NP + lj) * M2;
-#if SDPB_SYRK2_PREFETCH
-          // the LDS reads of the next row are issued before the MACs of the current one
-          uint32_t a0[M2], b0[M2], a1[M2], b1[M2];
-          piece_load<M2>(pa, a0);
-          piece_load<M2>(pb, b0);
+          if constexpr(SDPB_SYRK2_PREFETCH && M2 <= 6)
+            {
+              // the LDS reads of the next row are issued before the MACs of the current one
+              uint32_t a0[M2], b0[M2], a1[M2], b1[M2];
+              piece_load<M2>(pa, a0);
+              piece_load<M2>(pb, b0);
 #pragma unroll 1
-          for(int rr = 0; rr < RBG; rr += 2)
-            {
-              piece_load<M2>(pa + (rr + 1) * 16 * M2, a1);
-              piece_load<M2>(pb + (rr + 1) * 16 * M2, b1);
-              SyrkColumns<M2, 0>::run(a0, b0, c, h);
-              const int nx = rr + 2 < RBG ? rr + 2 : 0; // the read past the last row is dropped
-              piece_load<M2>(pa + nx * 16 * M2, a0);
-              piece_load<M2>(pb + nx * 16 * M2, b0);
-              SyrkColumns<M2, 0>::run(a1, b1, c, h);
+              for(int rr = 0; rr < RBG; rr += 2)
+                {
+                  piece_load<M2>(pa + (rr + 1) * 16 * M2, a1);
+                  piece_load<M2>(pb + (rr + 1) * 16 * M2, b1);
+                  SyrkColumns<M2, 0>::run(a0, b0, c, h);
+                  const int nx = rr + 2 < RBG ? rr + 2 : 0; // the read past the last row is dropped
+                  piece_load<M2>(pa + nx * 16 * M2, a0);
+                  piece_load<M2>(pb + nx * 16 * M2, b0);
+                  SyrkColumns<M2, 0>::run(a1, b1, c, h);
+                }
             }
-#else
-#pragma unroll SDPB_SYRK2_UNROLL
-          for(int rr = 0; rr < RBG; ++rr)
+          else
             {
-              uint32_t a[M2], b[M2];
-              piece_load<M2>(pa + rr * 16 * M2, a);
-              piece_load<M2>(pb + rr * 16 * M2, b);
-              SyrkColumns<M2, 0>::run(a, b, c, h);
+#pragma unroll 1
+              for(int rr = 0; rr < RBG; ++rr)
+                {
+                  uint32_t a[M2], b[M2];
+                  piece_load<M2>(pa + rr * 16 * M2, a);
+                  piece_load<M2>(pb + rr * 16 * M2, b);
+                  SyrkColumns<M2, 0>::run(a, b, c, h);
+                }
             }
-#endif
           syrk_fold<M2>(g2[g], c, h);
           store(buf ^ 1);
           __syncthreads();
           buf ^= 1;
         }
     }
-  if(i < N && j <= i)
+  if constexpr(SWEEPS == 3)
+    second_level(sweep, 0);
+  }
+  if constexpr(SWEEPS == 1)
     {
-      // second level: XX = X0X0 + (XtXt - X0X0 - X1X1) B2 + X1X1 B2^2 for X in (lo, hi, s)
-      uint32_t x[3][A];
 #pragma unroll
       for(int k = 0; k < 3; ++k)
-        {
-          sub_limbs<A2>(g2[3 * k + 2], g2[3 * k]);
-          sub_limbs<A2>(g2[3 * k + 2], g2[3 * k + 1]);
-#pragma unroll
-          for(int q = 0; q < A; ++q)
-            x[k][q] = q < A2 ? g2[3 * k][q < A2 ? q : 0] : 0u;
-          add_shifted<A, A2>(x[k], g2[3 * k + 2], 32 * M2 - 1, false);
-          add_shifted<A, A2>(x[k], g2[3 * k + 1], 64 * M2 - 2, false);
-        }
+        second_level(k, 3 * k);
+    }
+  if(i < N && j <= i)
+    {
       // first level: G = LL + (SS - LL - HH) B + HH B^2, B = 2^(32M-3)
       sub_limbs<A>(x[2], x[0]);
       sub_limbs<A>(x[2], x[1]);

@@ -116,7 +116,10 @@ inline const char *terminate_string(int r)
 // cost (the quantities the reference measures into block_timings: cholesky_ +
 // solve_ + syrk share, bigint_syrk/Readme.md:325-342; analogue of
 // compute_block_grid_mapping.hxx:58-183).  Deterministic, identical on every rank.
-inline std::vector<int> plan_block_owners(const std::vector<int> &dims, const std::vector<int> &num_points, int N, int world)
+// `measured`: per-block costs from an earlier run's block_timings file (read_block_costs.cxx:14-59);
+// empty -> the analytic model.
+inline std::vector<int> plan_block_owners(const std::vector<int> &dims, const std::vector<int> &num_points, int N, int world,
+                                          const std::vector<long long> &measured = {})
 {
   const int J = (int)dims.size();
   std::vector<double> cost(J);
@@ -126,6 +129,9 @@ inline std::vector<int> plan_block_owners(const std::vector<int> &dims, const st
       const double n0 = m * ((num_points[j] + 1) / 2), n1 = m * K - n0;
       cost[j] = P * P * P / 3 + P * P * N + P * (double)N * N / 2 + 8 * P * P + 5 * (n0 * n0 * n0 + n1 * n1 * n1);
     }
+  if((int)measured.size() == J)
+    for(int j = 0; j < J; ++j)
+      cost[j] = (double)measured[j];
   std::vector<int> order(J), owner(J, 0);
   for(int j = 0; j < J; ++j)
     order[j] = j;
@@ -177,6 +183,7 @@ public:
   virtual int limbs() const = 0;
   virtual int fx_frac_bits() const = 0;
   virtual double bench_op(const std::string &op, int a, int b, int reps) = 0;
+  virtual void block_timings(long long *microseconds) = 0;
   // operator-level entry points for parity tests
   virtual std::string op_scalar(const std::string &op, const char *a, const char *b) = 0;
   virtual std::string op_int_syrk(int rows, int cols, const char *ints_colmajor) = 0;
@@ -216,7 +223,7 @@ template <int NL> class Solver : public SolverBase
   static constexpr int ACCW = 2 * FX + 2;
   static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>(); // nine (FX/4)^2 products per row pair (k_syrk_fx2) instead of three (FX/2)^2
   // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
-  static constexpr int SYRK_RB = SYRK_TWO_LEVEL ? 32 : (FX <= 24 ? 16 : 8);
+  static constexpr int SYRK_RB = SYRK_TWO_LEVEL ? (FX >= 32 ? 16 : 32) : (FX <= 24 ? 16 : 8);
 
   // ---- problem shape -------------------------------------------------------
   int precision_, J_, N_, rank_, world_;
@@ -282,6 +289,7 @@ template <int NL> class Solver : public SolverBase
   std::unique_ptr<Comm> comm_;
   long host_syncs_ = 0;
   bool profile_ = false;
+  long profiled_iterations_ = 0;
   double max_runtime_s_ = std::numeric_limits<double>::infinity();
   std::chrono::steady_clock::time_point start_time_;
   bool started_ = false;
@@ -324,12 +332,13 @@ template <int NL> class Solver : public SolverBase
   };
 
 public:
-  Solver(int precision_bits, const std::vector<int> &dims, const std::vector<int> &num_points, int N, int rank, int world)
+  Solver(int precision_bits, const std::vector<int> &dims, const std::vector<int> &num_points, int N, int rank, int world,
+         const std::vector<long long> &block_costs = {})
       : precision_(precision_bits), J_((int)dims.size()), N_(N), rank_(rank), world_(world), dims_(dims), npts_(num_points)
   {
     if(N <= 0 || J_ <= 0)
       throw SolverError(4, "sdpb_hip_create: need at least one block and N >= 1");
-    owner_ = plan_block_owners(dims, num_points, N, world);
+    owner_ = plan_block_owners(dims, num_points, N, world, block_costs);
     {
       int dev = 0;
       hipDeviceProp_t prop;
@@ -1608,6 +1617,9 @@ public:
         start_time_ = std::chrono::steady_clock::now();
       }
     iteration_ += 1;
+    Timer whole(this, "iteration");
+    if(profile_)
+      profiled_iterations_ += 1;
     {
       // failure tag, rank 0's wall-clock verdict, SIGTERM seen on this rank
       const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start_time_).count();
@@ -1829,6 +1841,44 @@ public:
     return mw::to_decimal<NL>(download<NL>(io, 2, 1)[0]);
   }
 
+  // Per-block cost in microseconds per iteration, the quantity the reference measures into
+  // block_timings (compute_Q.cxx:40-53 per-block Cholesky + solve, plus the block's share of the
+  // syrk, bigint_syrk/Readme.md:325-342).  Blocks run batched on the GPU, so the measured STAGE
+  // times of the profiled iterations (sdpb_hip_set_profiling) are apportioned to the local blocks
+  // by each stage's operation count; blocks of other ranks get 0 (the caller sums over ranks).
+  void block_timings(long long *us) override
+  {
+    for(int j = 0; j < J_; ++j)
+      us[j] = 0;
+    auto stage = [&](const char *name) {
+      auto it = timers_ms_.find(name);
+      return it == timers_ms_.end() ? 0.0 : it->second;
+    };
+    const double t_chol = stage("initializeSchurComplementSolver.Q.cholesky"), t_solve = stage("initializeSchurComplementSolver.Q.solve"),
+                 t_syrk = stage("initializeSchurComplementSolver.Q.syrk"), t_step = stage("step"), t_total = stage("iteration");
+    if(profiled_iterations_ == 0 || t_total <= 0)
+      throw SolverError(4, "block_timings: no profiled iteration yet (sdpb_hip_set_profiling, then iterate)");
+    const double t_rest = std::max(0.0, t_total - t_chol - t_solve - t_syrk);
+    (void)t_step;
+    double s_chol = 0, s_solve = 0, s_syrk = 0, s_rest = 0;
+    std::vector<double> w_chol(Jl_), w_solve(Jl_), w_syrk(Jl_), w_rest(Jl_);
+    for(int l = 0; l < Jl_; ++l)
+      {
+        const BlockDesc &bd = blk_[l];
+        const double P = bd.P, n0 = bd.n[0], n1 = bd.n[1];
+        s_chol += w_chol[l] = P * P * P / 3;
+        s_solve += w_solve[l] = P * P * (double)N_ / 2;
+        s_syrk += w_syrk[l] = P;
+        s_rest += w_rest[l] = 30 * (n0 * n0 * n0 + n1 * n1 * n1) + 8 * P * P + 6 * P * (double)N_;
+      }
+    for(int l = 0; l < Jl_; ++l)
+      {
+        const double ms = t_chol * w_chol[l] / s_chol + t_solve * w_solve[l] / s_solve + t_syrk * w_syrk[l] / s_syrk
+                          + t_rest * w_rest[l] / s_rest;
+        us[local_[l]] = (long long)std::llround(1000.0 * ms / (double)profiled_iterations_);
+      }
+  }
+
   // sdpb_hip_bench_op: average HIP-event time of one kernel on synthetic operands (ms)
   double bench_op(const std::string &op, int a, int b, int reps) override
   {
@@ -1975,11 +2025,11 @@ public:
 };
 
 // one factory per compiled limb count (solver_nl.hip is built once per SDPB_NL)
-__attribute__((weak)) SolverBase *make_solver_6(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-__attribute__((weak)) SolverBase *make_solver_10(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-__attribute__((weak)) SolverBase *make_solver_16(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-__attribute__((weak)) SolverBase *make_solver_18(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-__attribute__((weak)) SolverBase *make_solver_24(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-__attribute__((weak)) SolverBase *make_solver_26(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
-__attribute__((weak)) SolverBase *make_solver_34(int, const std::vector<int> &, const std::vector<int> &, int, int, int);
+__attribute__((weak)) SolverBase *make_solver_6(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_10(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_16(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_18(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_24(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_26(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_34(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
 } // namespace sdpb

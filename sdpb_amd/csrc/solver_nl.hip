@@ -11,8 +11,8 @@
 namespace sdpb
 {
 SolverBase *SDPB_CAT(make_solver_, SDPB_NL)(int precision_bits, const std::vector<int> &dims, const std::vector<int> &num_points,
-                                             int N, int rank, int world)
+                                             int N, int rank, int world, const std::vector<long long> &block_costs)
 {
-  return new Solver<SDPB_NL>(precision_bits, dims, num_points, N, rank, world);
+  return new Solver<SDPB_NL>(precision_bits, dims, num_points, N, rank, world, block_costs);
 }
 } // namespace sdpb

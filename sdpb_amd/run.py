@@ -46,6 +46,8 @@ def _options(argv: Optional[List[str]] = None):
     ap.add_argument("--writeSolution", default="x,y", help="comma separated subset of x,y,X,Y,z")
     ap.add_argument("-i", "--initialCheckpointDir", default=None,
                     help="text checkpoint: a directory written with --writeSolution=x,y,X,Y (load_text_checkpoint.cxx:6-44)")
+    ap.add_argument("-c", "--checkpointDir", default=None,
+                    help="where block_timings is written and looked for (default: <sdpDir>.ck, as sdpb)")
     ap.add_argument("--verbosity", type=int, default=1)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--noFinalCheckpoint", action="store_true", help="accepted for compatibility")
@@ -148,7 +150,17 @@ def solve(argv: Optional[List[str]] = None) -> str:
                   detectPrimalFeasibleJump=int(o.detectPrimalFeasibleJump),
                   detectDualFeasibleJump=int(o.detectDualFeasibleJump))
     start = time.time()
-    solver = SDPSolver(sdp, o.precision, params, device=o.device, lib_path=o.lib)
+    # measured block costs of an earlier run balance the blocks over the GPUs
+    # (Block_Info/read_block_costs.cxx:14-59: the checkpoint's file wins over the SDP's)
+    ck_dir = o.checkpointDir or (o.sdpDir.rstrip("/") + ".ck")
+    costs = None
+    for cand in (os.path.join(ck_dir, "block_timings"), os.path.join(o.sdpDir, "block_timings")):
+        if os.path.isfile(cand):
+            with open(cand) as f:
+                costs = [int(t) for t in f.read().split()]
+            break
+    solver = SDPSolver(sdp, o.precision, params, device=o.device, lib_path=o.lib, block_costs=costs)
+    timing_run = costs is None   # run.cxx:442-453: iteration 1 is unrepresentative, iteration 2 is timed
     if o.initialCheckpointDir:
         load_text_checkpoint(solver, sdp, o.initialCheckpointDir)
     # --maxRuntime is tested inside the iteration, where the reference tests it
@@ -172,9 +184,18 @@ def solve(argv: Optional[List[str]] = None) -> str:
         itf.write("[")
         while reason is None:
             t_it = time.time()
+            if timing_run and solver.iteration == 1:
+                solver.set_profiling(True)
             if solver.iterate():
                 reason = solver.terminate_reason
                 break
+            if timing_run and solver.iteration == 2:
+                # write_timing.cxx:34-68: one integer per block and line, in <checkpointDir>/block_timings
+                solver.set_profiling(False)
+                timing_run = False
+                os.makedirs(ck_dir, exist_ok=True)
+                with open(os.path.join(ck_dir, "block_timings"), "w") as f:
+                    f.write("".join(f"{t}\n" for t in solver.block_timings()))
             rec = solver.scalars()
             now = time.time()
             itf.write(("," if solver.iteration > 1 else "") + "\n{ \"iteration\":%d, \"total_time\": %.3f, "

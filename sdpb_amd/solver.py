@@ -72,6 +72,11 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     size_p = ctypes.POINTER(ctypes.c_size_t)
     L.sdpb_hip_create.argtypes = [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    ll_p = ctypes.POINTER(ctypes.c_longlong)
+    L.sdpb_hip_create_with_costs.argtypes = [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ll_p, ctypes.POINTER(ctypes.c_void_p)]
+    L.sdpb_hip_block_timings.argtypes = [ctypes.c_void_p, ll_p]
+    L.sdpb_hip_plan_blocks_with_costs.argtypes = [ctypes.c_int, ll_p, ctypes.c_int, c_int_p]
     L.sdpb_hip_destroy.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_destroy.restype = None
     L.sdpb_hip_last_error.argtypes = [ctypes.c_void_p]
@@ -154,7 +159,8 @@ def plan_blocks(dims: List[int], num_points: List[int], N: int, world_size: int,
 class SDPSolver:
     def __init__(self, sdp: SDP, precision: int, params: Optional[dict] = None, device: int = -1,
                  rank: int = 0, world_size: int = 1, lib_path: Optional[str] = None,
-                 upload_all_blocks: bool = True, block_source: Optional[Callable] = None):
+                 upload_all_blocks: bool = True, block_source: Optional[Callable] = None,
+                 block_costs: Optional[List[int]] = None):
         """block_source(j) -> (bases_even_rows, bases_odd_rows, B float64 [P,N], c float64 [P]) supplies
         blocks lazily as arrays (bulk synthetic inputs); otherwise sdp.blocks[j] holds decimal strings."""
         self.L = load_library(lib_path)
@@ -163,9 +169,12 @@ class SDPSolver:
         self.rank, self.world_size = rank, world_size
         J = sdp.J
         h = ctypes.c_void_p()
-        rc = self.L.sdpb_hip_create(precision, J, (ctypes.c_int * J)(*sdp.dims),
-                                    (ctypes.c_int * J)(*sdp.num_points), sdp.N, device, rank, world_size,
-                                    ctypes.byref(h))
+        costs = (ctypes.c_longlong * J)(*[int(c) for c in block_costs]) if block_costs is not None else None
+        if block_costs is not None and len(block_costs) != J:   # read_block_costs.cxx:50-55
+            raise SDPBError(4, f"Incompatible number of entries in block_timings: expected {J} but found {len(block_costs)}")
+        rc = self.L.sdpb_hip_create_with_costs(precision, J, (ctypes.c_int * J)(*sdp.dims),
+                                               (ctypes.c_int * J)(*sdp.num_points), sdp.N, device, rank, world_size,
+                                               costs, ctypes.byref(h))
         if rc:
             raise SDPBError(rc, self.L.sdpb_hip_last_error(None).decode())
         self.h = h
@@ -370,6 +379,12 @@ class SDPSolver:
     def op_int_syrk(self, rows: int, cols: int, ints_colmajor) -> List[int]:
         txt = " ".join(str(v) for v in ints_colmajor).encode()
         return [int(s) for s in self._string(self.L.sdpb_hip_op_int_syrk, rows, cols, txt).split()]
+
+    def block_timings(self) -> List[int]:
+        """Microseconds per iteration for the blocks this rank owns (0 elsewhere); needs profiled iterations."""
+        out = (ctypes.c_longlong * self.sdp.J)()
+        self._chk(self.L.sdpb_hip_block_timings(self.h, out))
+        return list(out)
 
     def bench_op(self, op: str, a: int, b: int, reps: int = 3) -> float:
         """Average HIP-event time (ms) of one kernel of the iteration on synthetic operands."""

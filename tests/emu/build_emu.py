@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sdpb_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
-# only the mantissa widths the CPU tests use (the factories are weak symbols): 128, 512, 664, 768 bits
-LIMBS = (6, 18, 24, 26)
+# only the mantissa widths the CPU tests use (the factories are weak symbols): 128, 512, 664, 768, 1024 bits
+LIMBS = (6, 18, 24, 26, 34)
 CXX = os.environ.get("CXX", "g++")
 FLAGS = ["-O1", "-std=c++17", "-fPIC", "-fopenmp", "-x", "c++", "-I" + os.path.join(HERE, "include"),
          "-Wno-unknown-pragmas", "-Wno-attributes", "-DSDPB_NO_RCCL"]

@@ -27,7 +27,7 @@ def test_emulated_library_matches_reference_golden(name, limit):
 
 
 @pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (128, 70, 21, "3"), (512, 45, 18, None),
-                                                        (664, 20, 17, None)])
+                                                        (664, 20, 17, None), (1024, 40, 18, None), (1024, 40, 18, "2")])
 def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     import random
     if splits:
@@ -38,7 +38,7 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     o = Oracle(sdp, precision)
     fb = s.fx_frac_bits           # 32 FX - 7 with two Karatsuba levels (FX % 4 == 0), else 32 FX - 3
     fx = s.limbs - 2
-    assert fb == 32 * fx - (7 if fx % 4 == 0 and fx <= 24 else 3)
+    assert fb == 32 * fx - (7 if fx % 4 == 0 else 3)
     rng = random.Random(7)
     vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
     vals[5] = 0

@@ -173,3 +173,43 @@ def test_schur_solver_hook_for_approx_objective():
 @pytest.mark.gpu
 def test_schur_solver_hook_for_approx_objective_on_the_device():
     _schur_hook(libs.product_lib())
+
+
+def test_block_timings_are_written_read_and_balance_the_ranks(tmp_path):
+    """the timing run writes <checkpointDir>/block_timings (write_timing.cxx:34-68), the
+    next run reads it (read_block_costs.cxx:14-59) and plans the blocks on those costs."""
+    import ctypes
+    from sdpb_amd import run
+    from sdpb_amd.solver import load_library
+    sdp_dir = os.path.join(parity.GOLDEN, "dfibo", "sdp")
+    sdp, meta, _, _ = parity.load_case("dfibo")
+    ck = tmp_path / "ck"
+    argv = ["-s", sdp_dir, "-o", str(tmp_path / "out"), "-c", str(ck), "--precision", str(meta["precision"]), "--lib",
+            libs.emu_lib(), "--maxIterations", "3", "--verbosity", "0"]
+    run.solve(argv)
+    with open(ck / "block_timings") as f:
+        costs = [int(t) for t in f.read().split()]
+    assert len(costs) == sdp.J and all(c >= 0 for c in costs) and sum(costs) > 0
+    # larger blocks cost more (dfibo mixes num_points 1 and 4)
+    big = [c for c, k in zip(costs, sdp.num_points) if k == max(sdp.num_points)]
+    small = [c for c, k in zip(costs, sdp.num_points) if k == min(sdp.num_points)]
+    assert min(big) > max(small)
+    # the plan on measured costs is a balanced partition
+    L = load_library(libs.emu_lib())
+    owners = (ctypes.c_int * sdp.J)()
+    assert L.sdpb_hip_plan_blocks_with_costs(sdp.J, (ctypes.c_longlong * sdp.J)(*costs), 4, owners) == 0
+    loads = [sum(c for c, o in zip(costs, owners) if o == r) for r in range(4)]
+    assert set(owners) == {0, 1, 2, 3} and max(loads) - min(loads) <= max(costs)
+    # a solver created with those costs uses exactly that plan
+    s = SDPSolver(sdp, meta["precision"], meta["params"], rank=1, world_size=4, lib_path=libs.emu_lib(), block_costs=costs)
+    assert [s.block_owner(j) for j in range(sdp.J)] == list(owners)
+    s.close()
+    # second run: the file is consumed (no timing run, file untouched), results unchanged
+    before = os.path.getmtime(ck / "block_timings")
+    run.solve(argv[:3] + [str(tmp_path / "out2")] + argv[4:])
+    assert os.path.getmtime(ck / "block_timings") == before
+    with open(tmp_path / "out" / "out.txt") as a, open(tmp_path / "out2" / "out.txt") as b:
+        strip = lambda t: [ln for ln in t.splitlines() if not ln.startswith("Solver runtime")]  # noqa: E731
+        assert strip(a.read()) == strip(b.read())
+    with pytest.raises(SDPBError, match="Incompatible number of entries"):
+        SDPSolver(sdp, meta["precision"], lib_path=libs.emu_lib(), block_costs=costs[:-1])

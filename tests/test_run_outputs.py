@@ -90,9 +90,62 @@ def test_driver_writes_sdpb_result_files_emulated(tmp_path):
 
 
 def test_text_checkpoint_restart_continues_the_same_trajectory(tmp_path):
+    _checkpoint_restart(tmp_path, libs.emu_lib())
+
+
+@pytest.mark.gpu
+def test_text_checkpoint_restart_continues_the_same_trajectory_gpu(tmp_path):
+    _checkpoint_restart(tmp_path, None)
+
+
+@pytest.mark.gpu
+def test_sigterm_stops_the_device_run_gracefully_with_a_usable_checkpoint(tmp_path):
+    """run.cxx:332-355 + solve.cxx:99-104: SIGTERM -> finish the iteration in flight, write the text
+    checkpoint, terminate reason "SIGTERM signal received"; restarting from it continues the trajectory."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    out = tmp_path / "out"
+    argv = [a for a in _argv("singlet_cT", str(out)) if a]
+    k = argv.index("--maxIterations") if "--maxIterations" in argv else None
+    if k is not None:
+        del argv[k:k + 2]
+    p = subprocess.Popen([sys.executable, "-m", "sdpb_amd.run"] + argv + ["--maxIterations", "100000", "--verbosity", "1"],
+                         cwd=libs.ROOT, stdout=subprocess.PIPE, text=True)
+    seen = 0
+    for line in p.stdout:                      # wait until a few iterations have been printed
+        if line[:1].isdigit():
+            seen += 1
+            if seen == 5:
+                p.send_signal(signal.SIGTERM)
+                break
+    rest = p.stdout.read()
+    assert p.wait(timeout=300) == 0
+    assert "SIGTERM signal received" in rest
+    with open(out / "out.txt") as f:
+        assert 'terminateReason = "SIGTERM signal received"' in f.read()
+    with open(out / "iterations.json") as f:
+        done = json.load(f)
+    assert 5 <= len(done) < 170                 # stopped early, file is well-formed JSON
+    assert os.path.exists(out / "X_matrix_0.txt") and os.path.exists(out / "y.txt")
+    # restart from the checkpoint: the next iterations follow the reference trace
+    _, meta, iters, _ = parity.load_case("singlet_cT")
+    cont = [a for a in _argv("singlet_cT", str(tmp_path / "cont")) if a]
+    if "--maxIterations" in cont:
+        k = cont.index("--maxIterations")
+        del cont[k:k + 2]
+    run.solve(cont + ["--maxIterations", "3", "-i", str(out)])
+    with open(tmp_path / "cont" / "iterations.json") as f:
+        got = json.load(f)
+    for g, w in zip(got, iters[len(done):len(done) + 3]):
+        bad, _ = parity.compare_iteration(g, w, tol_bits=99)
+        assert not bad, bad
+
+
+def _checkpoint_restart(tmp_path, lib):
     """--writeSolution=x,y,X,Y then -i <dir>: 3 + 3 iterations equal 6 iterations
     up to the decimal round trip of the checkpoint files."""
-    lib = libs.emu_lib()
     base = _argv("1d-constraints", str(tmp_path / "full"), lib)
     it = base.index("--maxIterations") if "--maxIterations" in base else None
     def with_max(argv, n):
