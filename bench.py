@@ -87,8 +87,8 @@ def cpu_baseline(cfg_name: str, precision: int, seconds_budget: float = 45.0):
             probe_note = f"sdpb binary found but unusable ({type(e).__name__}: {e}); "
     else:
         probe_note = "no sdpb binary on $SDPB_BIN/PATH; "
-    from oracle.oracle import Oracle
-    cores = os.cpu_count() or 1
+    from oracle.oracle import Oracle, usable_cpus
+    cores = usable_cpus()   # cgroup quota and affinity, not just the logical CPU count
     # x0.25 (J=150, N=250, P_tot=10000): 1/29 of the full iteration by the MAC model, ~10 s of CPU per iteration
     scale = float(os.environ.get("SDPB_BENCH_CPU_SCALE", "0.25"))
     c = synthetic.config(cfg_name, scale)
@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SDPB_BENCH_WORKLOAD", "C4"))
     ap.add_argument("--scale", type=float, default=float(os.environ.get("SDPB_BENCH_SCALE", "1.0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib", default=None, help="developer aid: another gfx950 build of libsdpb_hip.so (A/B of kernel variants)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="developer aid, NOT a measurement: run rank 0 of an N-rank job on one GPU with the "
                          "other ranks' contributions faked as copies of its own (per-rank timing without xGMI)")
@@ -174,7 +175,7 @@ def main():
     sdp, source = synthetic.make_lazy(cfg["dims"], cfg["num_points"], cfg["N"], precision, cfg["seed"])
     t_setup = time.time()
     solver = SDPSolver(sdp, precision, device=local_rank, rank=rank, world_size=sim or world, upload_all_blocks=False,
-                       block_source=source)
+                       block_source=source, lib_path=args.lib)
     if world > 1:
         # the exchange runs on RCCL inside the library (its own stream, no host synchronisation);
         # torch.distributed only carries the 128-byte id and the timing barrier
@@ -261,7 +262,7 @@ def main():
         stages = {k: round(tp1[k] - tp0.get(k, 0.0), 3) for k in tp1 if not k.startswith(skip)}
         nl = solver.limbs
         from sdpb_amd.solver import copy_bandwidth_gbs
-        copy_gbs = copy_bandwidth_gbs(1 << 30, 5)
+        copy_gbs = copy_bandwidth_gbs(1 << 30, 5, lib_path=args.lib)
         out = {
             "metric": "interior-point iterations/sec at --precision 512",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

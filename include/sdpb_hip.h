@@ -73,11 +73,14 @@ int sdpb_hip_init_state(sdpb_hip_ctx *ctx);
 /* One pass of the loop body of SDP_Solver::run (run.cxx:380-435): objectives,
  * Cholesky of X and Y, bilinear pairings, residues and errors, feasibility/termination
  * test, then SDP_Solver::step.  *terminated = 1 when the reference loop would `break`
- * (reason via sdpb_hip_terminate_reason); maxRuntime and checkpointing stay with the
- * caller's loop.  Collective over all ranks. */
+ * (reason via sdpb_hip_terminate_reason); checkpointing stays with the caller's loop,
+ * --maxRuntime and the graceful stop are tested inside (sdpb_hip_set_max_runtime,
+ * sdpb_hip_request_stop).  Three host synchronisation points per call.  Collective over
+ * all ranks. */
 int sdpb_hip_iterate(sdpb_hip_ctx *ctx, int *terminated);
-/* SDP_Solver_Terminate_Reason (src/sdp_solve/SDP_Solver_Terminate_Reason.hxx:6-19) in
- * declaration order, -1 while running; the string is operator<<'s text
+/* SDP_Solver_Terminate_Reason (src/sdp_solve/SDP_Solver_Terminate_Reason.hxx:9-21) in
+ * declaration order (0 PrimalDualOptimal ... 5 MaxComplementarityExceeded, 6 MaxIterationsExceeded,
+ * 7 MaxRuntimeExceeded, 8 PrimalStepTooSmall, 9 DualStepTooSmall, 10 SIGTERM_Received), -1 while running; the string is operator<<'s text
  * (SDP_Solver_Terminate_Reason.cxx:4-45). */
 int sdpb_hip_terminate_reason(sdpb_hip_ctx *ctx);
 const char *sdpb_hip_terminate_string(sdpb_hip_ctx *ctx);

@@ -70,16 +70,44 @@ class OracleError(RuntimeError):
     pass
 
 
+def usable_cpus() -> int:
+    """Host cores this process may really use: min(cpu_count, affinity mask, cgroup CPU quota).
+    (A GPU box can show 256 logical CPUs while its container is limited to 16: 256 OpenMP threads
+    then run 16x slower than 16.)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    period = float(g.read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 class Oracle:
     """GMP-mpf restatement of the reference iteration, driven like the product solver."""
 
     def __init__(self, sdp, precision: int, params: dict | None = None, param_prec: int = 64,
                  threads: int = 0, block_source=None):
-        """threads: host threads for the block/column loops (0 = $ORACLE_THREADS or all cores;
+        """threads: host threads for the block/column loops (0 = $ORACLE_THREADS or all usable cores;
         results are bit-identical for any count).  block_source(j) -> (bases_even, bases_odd,
         B float64 [P,N], c float64 [P]) feeds blocks lazily (sdpb_amd.synthetic.make_lazy)."""
         from sdpb_amd.sdp_io import block_text  # pure-python I/O helper, no compute
         self.L = lib()
+        if not threads and not os.environ.get("ORACLE_THREADS"):
+            threads = usable_cpus()
         self.threads = self.L.orc_set_threads(int(threads))
         J = sdp.J
         dims = (ctypes.c_int * J)(*sdp.dims)

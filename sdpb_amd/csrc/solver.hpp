@@ -89,9 +89,9 @@ enum TerminateReason // SDP_Solver_Terminate_Reason.hxx
   DualFeasible,
   PrimalFeasibleJumpDetected,
   DualFeasibleJumpDetected,
+  MaxComplementarityExceeded,
   MaxIterationsExceeded,
   MaxRuntimeExceeded,
-  MaxComplementarityExceeded,
   PrimalStepTooSmall,
   DualStepTooSmall,
   SIGTERM_Received
@@ -103,9 +103,9 @@ inline const char *terminate_string(int r)
                                 "found dual feasible solution",
                                 "primal feasible jump detected",
                                 "dual feasible jump detected",
+                                "maxComplementarity exceeded",
                                 "maxIterations exceeded",
                                 "maxRuntime exceeded",
-                                "maxComplementarity exceeded",
                                 "primal step too small",
                                 "dual step too small",
                                 "SIGTERM signal received"};
@@ -223,7 +223,10 @@ template <int NL> class Solver : public SolverBase
   static constexpr int ACCW = 2 * FX + 2;
   static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>(); // nine (FX/4)^2 products per row pair (k_syrk_fx2) instead of three (FX/2)^2
   // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
-  static constexpr int SYRK_RB = SYRK_TWO_LEVEL ? (FX >= 32 ? 16 : 32) : (FX <= 24 ? 16 : 8);
+#ifndef SDPB_SYRK2_RBG
+#define SDPB_SYRK2_RBG (FX >= 32 ? 16 : 32)
+#endif
+  static constexpr int SYRK_RB = SYRK_TWO_LEVEL ? SDPB_SYRK2_RBG : (FX <= 24 ? 16 : 8);
 
   // ---- problem shape -------------------------------------------------------
   int precision_, J_, N_, rank_, world_;
@@ -253,6 +256,7 @@ template <int NL> class Solver : public SolverBase
   DevArray bases_, E_, Et_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_, eigD2_, eigE2_, cmby_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
+  DevArray part2_; // partial sums of the column norms (the Q chain may run beside the predictor, which uses part_)
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, lam2_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_, syrk_tiles_, colsum_partial_, syrk_part_;
   int num_cus_ = 256;
@@ -289,6 +293,7 @@ template <int NL> class Solver : public SolverBase
   std::unique_ptr<Comm> comm_;
   long host_syncs_ = 0;
   bool profile_ = false;
+  bool overlap_syrk_ = true; // SDPB_HIP_OVERLAP_SYRK=0 keeps the Q chain on the main stream (A/B measurements)
   long profiled_iterations_ = 0;
   double max_runtime_s_ = std::numeric_limits<double>::infinity();
   std::chrono::steady_clock::time_point start_time_;
@@ -542,6 +547,9 @@ private:
       xgather_.alloc(std::max(RES_WORDS, (size_t)(NL + 1) * N_) * world_);
     if(const char *e = std::getenv("SDPB_HIP_PROFILE"))
       profile_ = std::atoi(e) != 0;
+    if(const char *e = std::getenv("SDPB_HIP_OVERLAP_SYRK"))
+      overlap_syrk_ = std::atoi(e) != 0;
+    part2_.alloc((size_t)std::max(Jl_, 1) * N_, NL);
   }
 
   void set_default_params()
@@ -1140,15 +1148,20 @@ private:
   // out[n] = base[n] + sign * sum_blocks (M_j^T v_j)[n], summed over all ranks
   template <bool SQUARE> void gemv_t_all(const DevArray &MT, const DevArray &v, const DevArray *base, int sign, DevArray &out)
   {
-    launch(k_gemv_t_partial<NL, SQUARE>, dim3(cdiv(N_, WG), Jl_), dim3(WG), stream_, btB(MT), v.cptr(), part_.ptr(), d_blk_.p, N_);
+    gemv_t_all<SQUARE>(MT, v, base, sign, out, part_);
+  }
+  template <bool SQUARE>
+  void gemv_t_all(const DevArray &MT, const DevArray &v, const DevArray *base, int sign, DevArray &out, DevArray &part)
+  {
+    launch(k_gemv_t_partial<NL, SQUARE>, dim3(cdiv(N_, WG), Jl_), dim3(WG), stream_, btB(MT), v.cptr(), part.ptr(), d_blk_.p, N_);
     if(world_ == 1)
       {
-        launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part_.cptr(), Jl_, N_, base ? base->cptr() : out.cptr(),
+        launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part.cptr(), Jl_, N_, base ? base->cptr() : out.cptr(),
                base ? 1 : 0, sign, out.ptr());
         return;
       }
     // local sum, cross-rank sum, then base + sign*sum
-    launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part_.cptr(), Jl_, N_, out.cptr(), 0, 1, out.ptr());
+    launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part.cptr(), Jl_, N_, out.cptr(), 0, 1, out.ptr());
     allreduce_vec_sum(out, N_);
     launch(k_base_plus_signed<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, out.ptr(), base ? base->cptr() : out.cptr(), base ? 1 : 0, sign, N_);
   }
@@ -1212,10 +1225,24 @@ private:
       copy(BT_, PT_);
       trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_);
     }
+    // With one rank the whole Q chain — norms, fixed-point image, syrk, restore, Cholesky(Q) — moves
+    // to the side stream: the main stream goes straight on to the Q-independent part of the
+    // predictor (R, Z, the Schur right-hand side, L^{-1} dx, P^T dx: two dozen latency-bound
+    // launches), whose idle issue slots the VALU-bound syrk fills.  (With several ranks the chain
+    // contains collectives, which stay ordered on the one stream the communicator is used from.)
+    const bool side = overlap_syrk_ && world_ == 1;
+    if(side)
+      {
+        HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
+        HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
+      }
     {
+      std::unique_ptr<OnSideStream> on_side;
+      if(side)
+        on_side.reset(new OnSideStream(this));
       // syrk_Q, compute_Q.cxx:94-132
       Timer t(this, "initializeSchurComplementSolver.Q.syrk");
-      gemv_t_all<true>(PT_, x_, nullptr, 1, norms_); // norms_ = column norms^2 (Matrix_Normalizer.cxx:75-137)
+      gemv_t_all<true>(PT_, x_, nullptr, 1, norms_, side ? part2_ : part_); // norms_ = column norms^2 (Matrix_Normalizer.cxx:75-137)
       {
         mw::Ptr nr = norms_.ptr(), inv = invnorms_.ptr();
         foreach((size_t)N_, [=] __device__(size_t i) {
@@ -1257,8 +1284,16 @@ private:
       launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, acc_.p, acc_stride_, N_, Ptot_global_);
       launch(k_restore_Q<NL, FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_,
              norms_.cptr(), Q_.ptr(), qflags + 1);
+      if(side)
+        {
+          // Cholesky(Q) follows on the same (side) stream, look-ahead bulk on the third one
+          blocked_cholesky_lookahead(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags, stream_, stream_q2_);
+          HIP_CHECK(hipEventRecord(ev_q_done_, stream_));
+          q_pending_ = true;
+        }
     }
-    cholesky_Q_async();
+    if(!side)
+      cholesky_Q_async();
   }
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
   // that fills the last round of resident workgroups better; `part` grows on demand

@@ -86,3 +86,26 @@ def test_header_is_usable_from_c_and_cxx(tmp_path):
                             "-o", str(exe), "-L" + libdir, "-l:" + libname, "-Wl,-rpath," + libdir,
                             "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_terminate_reason_codes_follow_the_reference_enum():
+    """sdpb_hip_terminate_reason returns SDP_Solver_Terminate_Reason's enumerators in declaration
+    order (SDP_Solver_Terminate_Reason.hxx:9-21), so the shim can static_cast."""
+    from sdpb_amd.solver import SDPSolver
+    from tests import parity
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, meta["precision"], dict(meta["params"], maxIterations=1), lib_path=libs.emu_lib())
+    assert s.L.sdpb_hip_terminate_reason(s.h) == -1
+    assert not s.iterate() and s.iterate()
+    assert (s.L.sdpb_hip_terminate_reason(s.h), s.terminate_reason) == (6, "maxIterations exceeded")
+    s.reset()
+    s.set_max_runtime(0.0)
+    s.set_params(dict(maxIterations=100))
+    assert s.iterate()
+    assert (s.L.sdpb_hip_terminate_reason(s.h), s.terminate_reason) == (7, "maxRuntime exceeded")
+    s.set_max_runtime(1e9)
+    s.reset()
+    s.request_stop()
+    assert s.iterate()
+    assert (s.L.sdpb_hip_terminate_reason(s.h), s.terminate_reason) == (10, "SIGTERM signal received")
+    s.close()
