@@ -134,6 +134,39 @@ def _self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def dry_run(args, lib, rank, world):
+    import torch
+    import torch.distributed as dist
+    from sdpb_amd import synthetic
+    from sdpb_amd.solver import SDPSolver
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = synthetic.config(args.workload, args.scale)
+    sdp, source = synthetic.make_lazy(cfg["dims"], cfg["num_points"], cfg["N"], cfg["precision"], cfg["seed"])
+    solver = SDPSolver(sdp, cfg["precision"], rank=rank, world_size=world, upload_all_blocks=False, block_source=source,
+                       lib_path=lib)
+    if world > 1:
+        from sdpb_amd.distributed import make_collectives
+        solver.set_collectives(*make_collectives(torch.device("cpu")))
+    for _ in range(args.warmup + args.steps):
+        assert not solver.iterate(), solver.terminate_reason
+    obj = solver.scalar("P-obj")
+    if world > 1:
+        objs = [None] * world
+        dist.all_gather_object(objs, obj)
+        assert len(set(objs)) == 1, "ranks diverged"
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "interior-point iterations/sec at --precision 512", "value": None, "unit": "iterations/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "DRY_RUN_NOT_A_MEASUREMENT": True,
+                          "config": {"workload": f"{args.workload} x{args.scale}: J={sdp.J}, N={sdp.N}", "exchange": solver.comm_name},
+                          "P-obj": obj}), flush=True)
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +195,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     sim = args.simulate_world if world == 1 else 0
+    # Launch-plumbing dry run for the CPU test suite (tests/test_bench_launch.py): the ranks, the
+    # rendezvous, the exchange callbacks and the one JSON line, on the CPU EMULATION build over gloo.
+    # Its output is flagged DRY_RUN_NOT_A_MEASUREMENT and carries no timing claim.
+    dry = os.environ.get("SDPB_BENCH_DRYRUN_LIB")
+    if dry:
+        return dry_run(args, dry, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)

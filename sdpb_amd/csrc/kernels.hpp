@@ -733,6 +733,66 @@ __global__ void __launch_bounds__(WG) k_qsolve_panel(Batch Q, Batch Linv, mw::Pt
     }
 }
 
+// The same panel step with the dependent chain cut to 2 x (one product + a log2(PB)-level tree):
+// 1024-lane workgroups, lane (i, k) forms ONE product of row i's dot product and the PB partial
+// products of a row meet in an LDS tree.  The substitution is a chain of 2 N/PB such launches per
+// right-hand side, replicated on every GPU, so its length is what matters (49 -> ~20 us per launch).
+constexpr int QS2_T = PB * PB <= 1024 ? PB * PB : 1024;
+template <int NL, bool TRANS>
+__global__ void __launch_bounds__(QS2_T) k_qsolve_panel2(Batch Q, Batch Linv, mw::Ptr rhs, mw::Ptr out, int k0)
+{
+  static_assert(PB * PB <= 1024, "one lane per (row, column) of a panel");
+  const MatDesc dq = Q.d[0], di = Linv.d[0];
+  const int N = dq.rows, nb = di.rows, t = threadIdx.x;
+  const int i = t % PB, k = t / PB;
+  __shared__ Mw<NL> sx[PB], part[QS2_T];
+  if(t < nb)
+    sx[t] = mw::load<NL>(rhs, (size_t)k0 + t);
+  __syncthreads();
+  auto tree = [&]() __attribute__((always_inline)) {
+    for(int s = PB / 2; s > 0; s >>= 1)
+      {
+        __syncthreads();
+        if(k < s && k + s < PB)
+          part[t] = mw::add(part[t], part[t + s * PB]);
+      }
+    __syncthreads();
+  };
+  // xp = Linv_pp rhs_p (lower triangular; TRANS: its transpose)
+  {
+    Mw<NL> p = mw::zero<NL>();
+    if(i < nb && k < nb && (TRANS ? k >= i : k <= i))
+      p = mw::mul(TRANS ? mat_ld<NL>(Linv, di, k, i) : mat_ld<NL>(Linv, di, i, k), sx[k]);
+    part[t] = p;
+  }
+  tree();
+  if(t < nb)
+    {
+      sx[t] = part[t]; // every partial of column block 0 is read before this write (barrier in tree)
+      if(blockIdx.x == 0)
+        mw::store<NL>(out, (size_t)k0 + t, part[t]);
+    }
+  __syncthreads();
+  // rows outside the panel: rhs[r] -= sum_k L(r, k0 + k) xp[k]
+  const int first = TRANS ? 0 : k0 + nb, count = TRANS ? k0 : N - k0 - nb;
+  const int ri = blockIdx.x * PB + i;
+  {
+    Mw<NL> p = mw::zero<NL>();
+    if(ri < count && k < nb)
+      {
+        const int r = first + ri;
+        p = mw::mul(TRANS ? mat_ld<NL>(Q, dq, k0 + k, r) : mat_ld<NL>(Q, dq, r, k0 + k), sx[k]);
+      }
+    part[t] = p;
+  }
+  tree();
+  if(k == 0 && ri < count)
+    {
+      const size_t r = (size_t)first + ri;
+      mw::store<NL>(rhs, r, mw::sub(mw::load<NL>(rhs, r), part[t]));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Block-structure helpers shared by the SDP-specific kernels
 // ---------------------------------------------------------------------------
@@ -1346,9 +1406,10 @@ template <int M, int K> struct SyrkColumns
   }
 };
 // acc += sum_K (c[K] + h[K] 2^64) 2^(32K): three carry chains (low words, high words, overflows)
-template <int M> MW_HD void syrk_fold(uint32_t (&acc)[2 * M + 2], const uint64_t (&c)[2 * M - 1], const uint32_t (&h)[2 * M - 1])
+template <int M, int A> MW_HD void syrk_fold(uint32_t (&acc)[A], const uint64_t (&c)[2 * M - 1], const uint32_t (&h)[2 * M - 1])
 {
-  constexpr int A = 2 * M + 2, NC = 2 * M - 1;
+  static_assert(A >= 2 * M + 1, "column 2M-2 reaches limb 2M");
+  constexpr int NC = 2 * M - 1;
   const uint32_t zero = 0;
   mw::Carry cy;
   {
@@ -1413,7 +1474,7 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
       for(int rr = 0; rr < RB; ++rr)
         row(rr);
     }
-  syrk_fold<M>(acc, c, h);
+  syrk_fold<M, 2 * M + 2>(acc, c, h);
 }
 
 // acc(i,j) (i >= j, tiles of 16x16) = G(i,j) = sum_r a'(r,i) a'(r,j), rows r in
@@ -1819,15 +1880,25 @@ template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
 // (2 M2 + 2)-limb sum once.  The pieces of the NEXT pass are fetched from HBM/L2 into registers
 // while the MACs run and are written to the other LDS buffer when the pass ends (one barrier
 // per pass).  The nine sums are recombined once per output element after the row loop.
+// Tuning knobs of the row loop, measured on C4 (40 000 x 1000, 512 bits; profiles/r02e_syrk_staging_variants.txt):
+//   direct-to-LDS staging, rows unrolled x4        185.1 ms, no spills   <- default
+//   register staging,      rows unrolled x4        183.9 ms, 2 spilled VGPRs
+//   register staging,      explicit LDS prefetch   186.6 ms, 11 spilled VGPRs = 8.9 GB of scratch writes per launch
+//   direct-to-LDS staging, explicit LDS prefetch   192.6 ms, no spills
 #ifndef SDPB_SYRK2_PREFETCH
-#define SDPB_SYRK2_PREFETCH 1
+#define SDPB_SYRK2_PREFETCH 0
+#endif
+#ifndef SDPB_SYRK2_UNROLL
+#define SDPB_SYRK2_UNROLL 4 // row loop of the non-prefetching variant
 #endif
 template <int FX, int RBG>
 __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   k_syrk_fx2(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
-             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split)
+             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, const uint32_t *zero_piece)
 {
-  constexpr int M2 = FX / 4, M = FX / 2, A2 = 2 * M2 + 2, A = 2 * M + 2, W = 2 * FX + 2;
+  // A2 limbs hold the sum of one second-level product over a split's rows: pieces < 2^(32 M2), fewer
+  // than 2^32 rows, so the sum stays below 2^(64 M2 + 32)
+  constexpr int M2 = FX / 4, M = FX / 2, A2 = 2 * M2 + 1, A = 2 * M + 2, W = 2 * FX + 2;
   constexpr int NP = RBG * 16, GL = NP / WG; // pieces per operand per pass, per lane
   static_assert(NP % WG == 0, "a pass stages a whole number of pieces per lane");
   const uint32_t *fx = (const uint32_t *)__builtin_assume_aligned(fx_in, 16);
@@ -1852,8 +1923,18 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   constexpr int NG = FX >= 32 ? 3 : 9, SWEEPS = 9 / NG;
   uint32_t g2[NG][A2];
   uint32_t x[3][A];
-  uint32_t va[GL][M2], vb[GL][M2];
-  auto fetch = [&](int g, unsigned r0) __attribute__((always_inline)) {
+  // Staging of the NEXT pass.  16-byte pieces (M2 = 4) go HBM/L2 -> LDS directly
+  // (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16 B, exactly the [row][column] piece
+  // order), with no staging registers and no ds_write pass; the barrier that ends the pass drains
+  // them (vmcnt) before any wavefront reads the buffer.  Rows past the end and columns past N load
+  // a zero piece: they add nothing to any product.  Other piece sizes stage through registers.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK2_NO_GLDS)
+  constexpr bool DIRECT = (M2 == 4);
+#else
+  constexpr bool DIRECT = false;
+#endif
+  uint32_t va[DIRECT ? 1 : GL][M2], vb[DIRECT ? 1 : GL][M2];
+  auto fetch = [&](int g, unsigned r0, int into) __attribute__((always_inline)) {
 #pragma unroll
     for(int t = 0; t < GL; ++t)
       {
@@ -1862,26 +1943,44 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
         const unsigned r = r0 + rr;
         const int ca = ti * 16 + col, cb = tj * 16 + col;
         const bool ok = r < row_end;
-        // lanes outside the image read a valid piece and drop it: no divergent branches
         const uint32_t *row = fx + ((size_t)g * fx_stride + (size_t)(ok ? r : row_begin) * (size_t)N) * M2;
-        piece_load<M2>(row + (size_t)(ca < N ? ca : 0) * M2, va[t]);
-        piece_load<M2>(row + (size_t)(cb < N ? cb : 0) * M2, vb[t]);
-        const uint32_t ma = (ok && ca < N) ? 0xffffffffu : 0u, mb = (ok && cb < N) ? 0xffffffffu : 0u;
-#pragma unroll
-        for(int l = 0; l < M2; ++l)
+        if constexpr(DIRECT)
           {
-            va[t][l] &= ma; // rows past the end and columns past N: zero limbs,
-            vb[t][l] &= mb; // they add nothing to any product
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t *pa = (ok && ca < N) ? row + (size_t)ca * M2 : zero_piece;
+            const uint32_t *pb = (ok && cb < N) ? row + (size_t)cb * M2 : zero_piece;
+            const int wbase = (into * NP + t * WG + (int)(threadIdx.x & ~63u)) * M2; // this wavefront's 64 pieces
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa,
+                                             (__attribute__((address_space(3))) void *)(sa + wbase), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb,
+                                             (__attribute__((address_space(3))) void *)(sb + wbase), 16, 0, 0);
+#endif
+          }
+        else
+          {
+            // lanes outside the image read a valid piece and drop it: no divergent branches
+            piece_load<M2>(row + (size_t)(ca < N ? ca : 0) * M2, va[t]);
+            piece_load<M2>(row + (size_t)(cb < N ? cb : 0) * M2, vb[t]);
+            const uint32_t ma = (ok && ca < N) ? 0xffffffffu : 0u, mb = (ok && cb < N) ? 0xffffffffu : 0u;
+#pragma unroll
+            for(int l = 0; l < M2; ++l)
+              {
+                va[t][l] &= ma;
+                vb[t][l] &= mb;
+              }
           }
       }
   };
   auto store = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for(int t = 0; t < GL; ++t)
+    if constexpr(!DIRECT)
       {
-        const int e = threadIdx.x + t * WG;
-        piece_store<M2>(sa + (buf * NP + e) * M2, va[t]);
-        piece_store<M2>(sb + (buf * NP + e) * M2, vb[t]);
+#pragma unroll
+        for(int t = 0; t < GL; ++t)
+          {
+            const int e = threadIdx.x + t * WG;
+            piece_store<M2>(sa + (buf * NP + e) * M2, va[t]);
+            piece_store<M2>(sb + (buf * NP + e) * M2, vb[t]);
+          }
       }
   };
   // second level: XX = X0X0 + (XtXt - X0X0 - X1X1) B2 + X1X1 B2^2 for X = first-level operand k
@@ -1904,7 +2003,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
       g2[g][k] = 0;
   if(sweep > 0)
     __syncthreads(); // every wavefront has left the last pass of the previous sweep
-  fetch(sweep * NG, row_begin);
+  fetch(sweep * NG, row_begin, 0);
   store(0);
   __syncthreads();
   int buf = 0;
@@ -1913,7 +2012,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 #pragma unroll
       for(int g = 0; g < NG; ++g)
         {
-          fetch(sweep * NG + (g < NG - 1 ? g + 1 : 0), g < NG - 1 ? r0 : r0 + RBG);
+          fetch(sweep * NG + (g < NG - 1 ? g + 1 : 0), g < NG - 1 ? r0 : r0 + RBG, buf ^ 1);
           uint64_t c[2 * M2 - 1];
           uint32_t h[2 * M2 - 1];
 #pragma unroll
@@ -1943,7 +2042,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
             }
           else
             {
-#pragma unroll 1
+#pragma unroll SDPB_SYRK2_UNROLL
               for(int rr = 0; rr < RBG; ++rr)
                 {
                   uint32_t a[M2], b[M2];
@@ -1952,7 +2051,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
                   SyrkColumns<M2, 0>::run(a, b, c, h);
                 }
             }
-          syrk_fold<M2>(g2[g], c, h);
+          syrk_fold<M2, A2>(g2[g], c, h);
           store(buf ^ 1);
           __syncthreads();
           buf ^= 1;

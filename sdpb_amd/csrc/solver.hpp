@@ -287,13 +287,15 @@ template <int NL> class Solver : public SolverBase
   };
   static_assert(R_COUNT <= X_MAXSLOTS, "result block too large for XOps");
   static constexpr size_t RES_WORDS = (size_t)(NL + 1) * R_COUNT + X_EXTRA;
-  DevBuf<uint32_t> resbuf_, xgather_;
+  DevBuf<uint32_t> resbuf_, xgather_, zero_piece_; // zero_piece_: what k_syrk_fx2 stages for rows/columns outside the image
   std::vector<M> res_host_ = std::vector<M>(R_COUNT);
   uint32_t xw_host_[X_EXTRA] = {0xffffffffu, 0, 0, 0};
   std::unique_ptr<Comm> comm_;
   long host_syncs_ = 0;
   bool profile_ = false;
-  bool overlap_syrk_ = true; // SDPB_HIP_OVERLAP_SYRK=0 keeps the Q chain on the main stream (A/B measurements)
+  // SDPB_HIP_OVERLAP_SYRK=1 moves the Q chain to the side stream (experiment, measured on C4: the VALU-bound
+  // syrk slows by 8 ms when it shares the CUs, the step by 4 ms: profiles/r02d_overlap_syrk.txt) -> off
+  bool overlap_syrk_ = false;
   long profiled_iterations_ = 0;
   double max_runtime_s_ = std::numeric_limits<double>::infinity();
   std::chrono::steady_clock::time_point start_time_;
@@ -352,8 +354,18 @@ public:
       num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     HIP_CHECK(hipStreamCreate(&stream_));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream_q_, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream_q2_, hipStreamNonBlocking));
+    {
+      // The side stream carries latency-bound dependent chains (Cholesky(Q): 1000 pivots in a row)
+      // next to throughput work on the main stream: at high priority its small launches are
+      // dispatched as soon as they are ready instead of queueing behind full-chip kernels.
+      int least = 0, greatest = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      int prio = greatest;
+      if(const char *e = std::getenv("SDPB_HIP_SIDE_PRIORITY")) // 0: same priority as the main stream (A/B)
+        prio = std::atoi(e) ? greatest : 0;
+      HIP_CHECK(hipStreamCreateWithPriority(&stream_q_, hipStreamNonBlocking, prio));
+      HIP_CHECK(hipStreamCreateWithPriority(&stream_q2_, hipStreamNonBlocking, prio));
+    }
     HIP_CHECK(hipEventCreateWithFlags(&ev_la_strip_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_la_bulk_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&ev_q_ready_));
@@ -543,6 +555,7 @@ private:
     flags2_.alloc((size_t)2 * std::max(Jl_, 1));
     flags3_.alloc((size_t)std::max(Jl_, 1));
     resbuf_.alloc(RES_WORDS);
+    zero_piece_.alloc(64);
     if(world_ > 1)
       xgather_.alloc(std::max(RES_WORDS, (size_t)(NL + 1) * N_) * world_);
     if(const char *e = std::getenv("SDPB_HIP_PROFILE"))
@@ -1225,11 +1238,11 @@ private:
       copy(BT_, PT_);
       trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_);
     }
-    // With one rank the whole Q chain — norms, fixed-point image, syrk, restore, Cholesky(Q) — moves
-    // to the side stream: the main stream goes straight on to the Q-independent part of the
-    // predictor (R, Z, the Schur right-hand side, L^{-1} dx, P^T dx: two dozen latency-bound
-    // launches), whose idle issue slots the VALU-bound syrk fills.  (With several ranks the chain
-    // contains collectives, which stay ordered on the one stream the communicator is used from.)
+    // Optional (off, see overlap_syrk_): with one rank the whole Q chain — norms, fixed-point image,
+    // syrk, restore, Cholesky(Q) — can run on the side stream while the main stream goes on to the
+    // Q-independent part of the predictor (R, Z, the Schur right-hand side, L^{-1} dx, P^T dx).
+    // (With several ranks the chain contains collectives, which stay ordered on the one stream the
+    // communicator is used from.)
     const bool side = overlap_syrk_ && world_ == 1;
     if(side)
       {
@@ -1314,7 +1327,7 @@ private:
       }
     if constexpr(SYRK_TWO_LEVEL)
       launch(k_syrk_fx2<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
-             tiles_dev, ntile, nsplit, rps);
+             tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
     else
       launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
              tiles_dev, ntile, nsplit, rps);
@@ -1390,14 +1403,22 @@ private:
         {
           const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
           Batch iv{LiQ_.ptr(), d_qdiag_.p + p, 1};
-          launch(k_qsolve_panel<NL, false>, dim3(std::max(1u, cdiv(rest, QS_ROWS))), dim3(WG), stream_, QB(), iv, dy_.ptr(), qtmpv_.ptr(),
-                 k0);
+          if constexpr(PB * PB <= 1024)
+            launch(k_qsolve_panel2<NL, false>, dim3(std::max(1u, cdiv(rest, PB))), dim3(QS2_T), stream_, QB(), iv, dy_.ptr(), qtmpv_.ptr(),
+                   k0);
+          else
+            launch(k_qsolve_panel<NL, false>, dim3(std::max(1u, cdiv(rest, QS_ROWS))), dim3(WG), stream_, QB(), iv, dy_.ptr(),
+                   qtmpv_.ptr(), k0);
         }
       for(int p = q_panels_ - 1; p >= 0; --p)
         {
           const int k0 = p * q_nb_;
           Batch iv{LiQ_.ptr(), d_qdiag_.p + p, 1};
-          launch(k_qsolve_panel<NL, true>, dim3(std::max(1u, cdiv(k0, QS_ROWS))), dim3(WG), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(), k0);
+          if constexpr(PB * PB <= 1024)
+            launch(k_qsolve_panel2<NL, true>, dim3(std::max(1u, cdiv(k0, PB))), dim3(QS2_T), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(), k0);
+          else
+            launch(k_qsolve_panel<NL, true>, dim3(std::max(1u, cdiv(k0, QS_ROWS))), dim3(WG), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(),
+                   k0);
         }
     }
     {

@@ -151,6 +151,17 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
   *s = nullptr;
   return hipSuccess;
 }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int)
+{
+  *s = nullptr;
+  return hipSuccess;
+}
+inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest)
+{
+  *least = 0;
+  *greatest = -1;
+  return hipSuccess;
+}
 inline hipError_t hipEventCreate(hipEvent_t *e)
 {
   *e = new hipEmuEvent;
