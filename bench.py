@@ -295,7 +295,7 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_k_syrk_fx.json")
         if os.path.exists(pmc) and args.workload == "C4" and args.scale == 1.0 and world == 1:
-            with open(pmc) as f:
+            with open(pmc) as f:   # rocprofv3 --pmc cannot run inside this process: committed measurement of this command
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         skip = ("kernel.", "host_syncs", "iterations")
         stages = {k: round(tp1[k] - tp0.get(k, 0.0), 3) for k in tp1 if not k.startswith(skip)}
@@ -316,6 +316,8 @@ def main():
             "host_syncs_per_step": (syncs1 - syncs0) / args.steps,
             "roofline": {"bound": "hbm", "kernel": "k_syrk_fx", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r02_pmc_k_syrk_fx.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, FETCH_SIZE x2 per MI355X_MICROARCH.md)" if traffic else None,
                          "measured_copy_peak": copy_gbs,
                          "launch_ms": 1000.0 * k_avg_s, "algorithmic_bytes_per_launch": k_bytes,
                          "limb_mac_per_s": k_macs / k_avg_s if k_avg_s > 0 else 0.0,

@@ -322,6 +322,7 @@ template <int NL> class Solver : public SolverBase
   hipEvent_t ev_q_ready_ = nullptr, ev_q_done_ = nullptr, ev_la_strip_ = nullptr, ev_la_bulk_ = nullptr;
   hipStream_t stream_q2_ = nullptr; // bulk updates of the look-ahead Cholesky(Q)
   bool q_pending_ = false;
+  bool single_stream_ = false;
   hipEvent_t ev_syrk0_ = nullptr, ev_syrk1_ = nullptr;
   bool syrk_events_pending_ = false;
   double syrk_kernel_ms_ = 0;
@@ -363,8 +364,17 @@ public:
       int prio = greatest;
       if(const char *e = std::getenv("SDPB_HIP_SIDE_PRIORITY")) // 0: same priority as the main stream (A/B)
         prio = std::atoi(e) ? greatest : 0;
-      HIP_CHECK(hipStreamCreateWithPriority(&stream_q_, hipStreamNonBlocking, prio));
-      HIP_CHECK(hipStreamCreateWithPriority(&stream_q2_, hipStreamNonBlocking, prio));
+      // SDPB_HIP_SINGLE_STREAM=1: everything on the main stream (debugging aid; a GPU test asserts that
+      // the concurrent schedule gives bit-identical iterations, i.e. no ordering is left to chance)
+      if(const char *e = std::getenv("SDPB_HIP_SINGLE_STREAM"))
+        single_stream_ = std::atoi(e) != 0;
+      if(single_stream_)
+        stream_q_ = stream_q2_ = stream_;
+      else
+        {
+          HIP_CHECK(hipStreamCreateWithPriority(&stream_q_, hipStreamNonBlocking, prio));
+          HIP_CHECK(hipStreamCreateWithPriority(&stream_q2_, hipStreamNonBlocking, prio));
+        }
     }
     HIP_CHECK(hipEventCreateWithFlags(&ev_la_strip_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_la_bulk_, hipEventDisableTiming));
@@ -385,9 +395,9 @@ public:
       (void)hipEventDestroy(ev_la_strip_);
     if(ev_la_bulk_)
       (void)hipEventDestroy(ev_la_bulk_);
-    if(stream_q2_)
+    if(stream_q2_ && !single_stream_)
       (void)hipStreamDestroy(stream_q2_);
-    if(stream_q_)
+    if(stream_q_ && !single_stream_)
       (void)hipStreamDestroy(stream_q_);
     if(ev_syrk0_)
       (void)hipEventDestroy(ev_syrk0_);

@@ -109,3 +109,18 @@ def test_terminate_reason_codes_follow_the_reference_enum():
     assert s.iterate()
     assert (s.L.sdpb_hip_terminate_reason(s.h), s.terminate_reason) == (10, "SIGTERM signal received")
     s.close()
+
+
+def test_integration_shim_helpers_compile_and_round_trip_with_real_gmp(tmp_path):
+    """INTEGRATION.md's put/get on a real mpf_t (tests/shim/mpf_shim_check.cpp) against the library's
+    binary ABI: g++ + libgmp + the emulation build (the gfx950 library exports the same entry points)."""
+    import subprocess
+    lib = libs.emu_lib()
+    exe = tmp_path / "mpf_shim_check"
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I/opt/conda/include",
+                        os.path.join(ROOT, "tests", "shim", "mpf_shim_check.cpp"), "-o", str(exe), "-L" + os.path.dirname(lib),
+                        "-l:" + os.path.basename(lib), "-Wl,-rpath," + os.path.dirname(lib), "-l:libgmp.so.10"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "round-trip exactly" in r.stdout, r.stdout + r.stderr

@@ -224,3 +224,22 @@ def test_three_host_synchronisation_points_per_iteration_on_the_device():
         assert not s.iterate()
     assert s.host_syncs == 9
     s.close()
+
+
+def test_concurrent_streams_give_the_same_bits_as_one_stream(monkeypatch):
+    """Three streams (main; Y chain / Cholesky(Q) / dual step length; look-ahead bulk) versus everything
+    on one stream (SDPB_HIP_SINGLE_STREAM=1): identical iterations to the last bit, so no result
+    depends on an ordering the events do not enforce."""
+    c = _shape("C4", 0.25)
+    traces = []
+    for single in ("0", "1"):
+        monkeypatch.setenv("SDPB_HIP_SINGLE_STREAM", single)
+        sdp, s, _ = _pair(c, oracle=False)
+        t = []
+        for _ in range(3):
+            assert not s.iterate()
+            t.append(s.scalars())
+        t.append(s.array("dy")[:64])
+        traces.append(t)
+        s.close()
+    assert traces[0] == traces[1]
