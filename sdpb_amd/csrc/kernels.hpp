@@ -957,6 +957,126 @@ __global__ void __launch_bounds__(WG)
   mw::store<NL>(dx, (size_t)bl.voff + p, acc);
 }
 
+// The same right-hand side with the work of one (block, (r,s) pair) spread over a workgroup: lane
+// (k, g) owns sample point k and every G-th basis row i; per row it forms
+// W(i,k) = sum_l Z(rb rs + i, cb rs + l) q(l,k) and adds W(i,k) q(i,k) to its partial column sum
+// (the Z operand is a broadcast across the lanes of a group, q is read along k).  The dependent
+// chain per lane is 2 (rs/G)(rs + 1) products instead of 2 rs (rs + 1) (C4: 168 instead of 840), which
+// is what this latency-bound kernel costs: 3.0 -> 0.4 ms per launch.  grid (max pairs, blocks).
+template <int NL>
+__global__ void __launch_bounds__(WG)
+  k_schur_rhs2(Batch bases, Batch Z, mw::CPtr dres, mw::Ptr dx, const BlockDesc *blk)
+{
+  const int j = blockIdx.y, t = threadIdx.x;
+  const BlockDesc bl = blk[j];
+  const int pair = blockIdx.x;
+  if(pair >= bl.m * (bl.m + 1) / 2)
+    return;
+  int cb = 0;
+  while((cb + 1) * (cb + 2) / 2 <= pair)
+    ++cb;
+  const int rb = pair - cb * (cb + 1) / 2;
+  const int K = bl.K, KL = K < WG ? K : WG, G = WG / KL;
+  const int kk = t % KL, g = t / KL;
+  __shared__ Mw<NL> part[WG];
+  for(int k0 = 0; k0 < K; k0 += KL)
+    {
+      const int k = k0 + kk;
+      Acc<NL> colsum = mw::acc_zero<NL>();
+      if(g < G && k < K)
+        for(int b = 0; b < 2; ++b)
+          {
+            const int rs = bl.rows[b];
+            const MatDesc dz = Z.d[2 * j + b], dbs = bases.d[2 * j + b];
+            for(int i = g; i < rs; i += G)
+              {
+                Acc<NL> zq = mw::acc_zero<NL>();
+                for(int l = 0; l < rs; ++l)
+                  mw::acc_fma(zq, mat_ld<NL>(Z, dz, rb * rs + i, cb * rs + l), mat_ld<NL>(bases, dbs, l, k));
+                mw::acc_fma(colsum, mw::acc_result(zq), mat_ld<NL>(bases, dbs, i, k));
+              }
+          }
+      part[t] = mw::acc_result(colsum);
+      __syncthreads();
+      if(g == 0 && k < K)
+        {
+          const size_t p = (size_t)bl.voff + (size_t)pair * K + k;
+          Acc<NL> sum = mw::acc_zero<NL>();
+          mw::acc_add(sum, mw::load<NL>(dres, p), 1u);
+          for(int gg = 0; gg < G; ++gg)
+            mw::acc_add(sum, part[gg * KL + kk], 1u);
+          mw::store<NL>(dx, p, mw::acc_result(sum));
+        }
+      __syncthreads();
+    }
+}
+
+// x := L^{-1} x (TRANS: L^{-T} x) for one vector per block, all panels inside ONE workgroup
+// (the row-vector solves of solve_schur_complement_equation.cxx:24-31,76-78 were four launches of the
+// matrix kernel with a single row each: a chain of P_j dependent products in one lane).  Per panel
+//   t = x_p - L(p, other) x(other)   32 outputs, each dot product split over 8 lanes + LDS tree
+//   x_p = Linv_pp t                  (TRANS: Linv_pp^T), same split
+// Forward runs the panels upwards and "other" = the panels already solved (columns < k0); backward
+// runs them downwards with rows > k0 + nb of L^T.  X.d[q] is a 1 x P row descriptor.
+template <int NL, bool TRANS>
+__global__ void __launch_bounds__(WG) k_vec_trsm(Batch L, Batch Li, Batch X)
+{
+  const int q = blockIdx.x, t = threadIdx.x;
+  const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
+  const int n = dl.rows;
+  if(n == 0)
+    return;
+  constexpr int SEG = WG / PB; // lanes per output
+  const int i = t % PB, seg = t / PB;
+  const int panels = (n + PB - 1) / PB;
+  __shared__ Mw<NL> sx[PB], part[WG];
+  auto vec = [&](int r) { return (size_t)dx.off + (size_t)r * dx.ld; }; // element r of the 1 x P row
+  for(int pp = 0; pp < panels; ++pp)
+    {
+      const int p = TRANS ? panels - 1 - pp : pp;
+      const int k0 = p * PB, nb = n - k0 < PB ? n - k0 : PB;
+      // (1) t_i = x(k0+i) - sum over the solved part
+      Acc<NL> acc = mw::acc_zero<NL>();
+      if(i < nb)
+        {
+          const int lo = TRANS ? k0 + nb : 0, hi = TRANS ? n : k0;
+          for(int k = lo + seg; k < hi; k += SEG)
+            {
+              const Mw<NL> l = TRANS ? mat_ld<NL>(L, dl, k, k0 + i) : mat_ld<NL>(L, dl, k0 + i, k);
+              mw::acc_fms(acc, l, mw::load<NL>(X.p, vec(k)));
+            }
+          if(seg == 0)
+            mw::acc_add(acc, mw::load<NL>(X.p, vec(k0 + i)));
+        }
+      part[t] = mw::acc_result(acc);
+      __syncthreads();
+      if(t < nb)
+        {
+          Acc<NL> s = mw::acc_zero<NL>();
+          for(int gsg = 0; gsg < SEG; ++gsg)
+            mw::acc_add(s, part[gsg * PB + t]);
+          sx[t] = mw::acc_result(s);
+        }
+      __syncthreads();
+      // (2) x_p = Linv_pp t (lower triangular; TRANS: its transpose)
+      acc = mw::acc_zero<NL>();
+      if(i < nb)
+        for(int k = seg; k < nb; k += SEG)
+          if(TRANS ? k >= i : k <= i)
+            mw::acc_fma(acc, TRANS ? mat_ld<NL>(Li, di, k0 + k, k0 + i) : mat_ld<NL>(Li, di, k0 + i, k0 + k), sx[k]);
+      part[t] = mw::acc_result(acc);
+      __syncthreads();
+      if(t < nb)
+        {
+          Acc<NL> s = mw::acc_zero<NL>();
+          for(int gsg = 0; gsg < SEG; ++gsg)
+            mw::acc_add(s, part[gsg * PB + t]);
+          mw::store<NL>(X.p, vec(k0 + t), mw::acc_result(s));
+        }
+      __syncthreads(); // the solved entries are read from global memory by the next panel
+    }
+}
+
 // part[j*N + n] = sum_p MT_j(n,p) * v_j[p]  (square: MT^2) — per-block partials of
 // B^T x (compute_primal_residues_and_error_p_b_Bx.cxx:26-28), P^T dx
 // (solve_schur_complement_equation.cxx:33-35) and the column norms^2 of P
@@ -2751,6 +2871,39 @@ __global__ void __launch_bounds__(WG)
           out[(size_t)k * elems + i] = (uint32_t)s;
           carry = s >> 32;
         }
+    }
+}
+// The same pair for the Q' accumulators: only the lower triangle (i >= j) and the N column sums
+// behind it carry information, so only those N(N+1)/2 + N entries per plane travel (half the
+// message).  Packed entry of (i, j): j N - j (j - 1) / 2 + (i - j); column sum i: N(N+1)/2 + i.
+// grid (cdiv(N, WG), N + 1): blockIdx.y = column j, j == N is the row of column sums.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(WG) k_widen_tri_u64(const uint32_t *acc, size_t acc_stride, int N, int planes, unsigned long long *out)
+{
+  const int i = blockIdx.x * WG + threadIdx.x, j = blockIdx.y;
+  if(i >= N || (j < N && i < j))
+    return;
+  const size_t T = (size_t)N * (N + 1) / 2 + N;
+  const size_t src = j < N ? (size_t)i + (size_t)j * N : (size_t)N * N + i;
+  const size_t dst = j < N ? (size_t)j * N - (size_t)j * (j - 1) / 2 + (size_t)(i - j) : (size_t)N * (N + 1) / 2 + i;
+  for(int k = 0; k < planes; ++k)
+    out[(size_t)k * T + dst] = acc[(size_t)k * acc_stride + src];
+}
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(WG) k_narrow_tri_carry(const unsigned long long *in, int N, int planes, uint32_t *acc, size_t acc_stride)
+{
+  const int i = blockIdx.x * WG + threadIdx.x, j = blockIdx.y;
+  if(i >= N || (j < N && i < j))
+    return;
+  const size_t T = (size_t)N * (N + 1) / 2 + N;
+  const size_t dst = j < N ? (size_t)i + (size_t)j * N : (size_t)N * N + i;
+  const size_t src = j < N ? (size_t)j * N - (size_t)j * (j - 1) / 2 + (size_t)(i - j) : (size_t)N * (N + 1) / 2 + i;
+  unsigned long long carry = 0;
+  for(int k = 0; k < planes; ++k)
+    {
+      const unsigned long long s = in[(size_t)k * T + src] + carry;
+      acc[(size_t)k * acc_stride + dst] = (uint32_t)s;
+      carry = s >> 32;
     }
 }
 } // namespace sdpb

@@ -249,7 +249,7 @@ template <int NL> class Solver : public SolverBase
   // blocked Cholesky(Q): per panel descriptors
   DevBuf<MatDesc> d_qdiag_, d_rowP_; // diagonal blocks of Q; dx as 1 x P row vectors
   int q_nb_ = 0, q_panels_ = 0;
-  int max_n_ = 0, max_q_ = 0, max_P_ = 0;
+  int max_n_ = 0, max_q_ = 0, max_P_ = 0, max_pairs_ = 1;
 
   // ---- device arrays ---------------------------------------------------------
   DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
@@ -479,6 +479,7 @@ private:
         off_bt += (size_t)N_ * bd.P;
         Ptot_ += bd.P;
         max_P_ = std::max(max_P_, bd.P);
+        max_pairs_ = std::max(max_pairs_, m * (m + 1) / 2);
       }
     Jl_ = (int)local_.size();
     psd_elems_ = off_psd;
@@ -559,7 +560,7 @@ private:
     syrk_tiles_.upload(syrk_tile_order(N_));
     if(world_ > 1)
       {
-        acc64_.alloc(acc_stride_ * ACCW);
+        acc64_.alloc(((size_t)N_ * (N_ + 1) / 2 + N_) * ACCW);
       }
     flags_.alloc((size_t)2 * std::max(Jl_, 1) + 4);
     flags2_.alloc((size_t)2 * std::max(Jl_, 1));
@@ -1361,11 +1362,12 @@ private:
   // exact cross-GPU sum of the fixed-point Q' images
   void reduce_Q_accumulators()
   {
-    const size_t words = acc_stride_ * ACCW;
-    launch(k_widen_u64<0>, dim3(std::min<unsigned>(cdiv(words, WG), 8192)), dim3(WG), stream_, (const uint32_t *)acc_.p, words, acc64_.p);
-    comm().allreduce_sum_u64(acc64_.p, words, stream_);
-    launch(k_narrow_carry<0>, dim3(std::min<unsigned>(cdiv(acc_stride_, WG), 8192)), dim3(WG), stream_, (const unsigned long long *)acc64_.p,
-           acc_stride_, ACCW, acc_.p);
+    // lower triangle + column sums only: (N(N+1)/2 + N) entries x ACCW planes of 64-bit lanes
+    const size_t T = (size_t)N_ * (N_ + 1) / 2 + N_;
+    const dim3 grid(cdiv(N_, WG), N_ + 1);
+    launch(k_widen_tri_u64<0>, grid, dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_, (int)ACCW, acc64_.p);
+    comm().allreduce_sum_u64(acc64_.p, T * ACCW, stream_);
+    launch(k_narrow_tri_carry<0>, grid, dim3(WG), stream_, (const unsigned long long *)acc64_.p, N_, (int)ACCW, acc_.p, acc_stride_);
   }
   // El::Cholesky(UPPER,Q) (initialize_schur_complement_solver.cxx:95-103), stored here
   // as the lower factor L = U^T (blocked, see kernels.hpp).  The factorisation is a long
@@ -1398,7 +1400,8 @@ private:
   {
     {
       Timer t(this, "searchDirection.solve.dx_Linv");
-      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, Batch{dx_.ptr(), d_rowP_.p, Jl_}, 1, max_P_); // dx^T L^{-T}
+      // dx := L^{-1} dx, one workgroup per block runs all panels (k_vec_trsm)
+      launch(k_vec_trsm<NL, false>, dim3(Jl_), dim3(WG), stream_, schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, Batch{dx_.ptr(), d_rowP_.p, Jl_});
     }
     {
       Timer t(this, "searchDirection.solve.dy_PTdx");
@@ -1437,7 +1440,8 @@ private:
     }
     {
       Timer t(this, "searchDirection.solve.dx_LTinv");
-      trsm_rln(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, Batch{dx_.ptr(), d_rowP_.p, Jl_}, 1, max_P_); // dx^T L^{-1}
+      // dx := L^{-T} dx
+      launch(k_vec_trsm<NL, true>, dim3(Jl_), dim3(WG), stream_, schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, Batch{dx_.ptr(), d_rowP_.p, Jl_});
     }
   }
 
@@ -1463,7 +1467,7 @@ private:
     {
       // dx = -d - Tr(A_p Z) ; dy = p
       Timer t(this, "searchDirection.schur_RHS");
-      launch(k_schur_rhs<NL>, dim3(cdiv(max_P_, WG), Jl_), dim3(WG), stream_, basesB(), psd(Z_), dres_.cptr(), dx_.ptr(), d_blk_.p);
+      launch(k_schur_rhs2<NL>, dim3(max_pairs_, Jl_), dim3(WG), stream_, basesB(), psd(Z_), dres_.cptr(), dx_.ptr(), d_blk_.p);
     }
     solve_schur_complement_equation();
     {
