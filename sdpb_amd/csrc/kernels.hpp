@@ -1105,16 +1105,29 @@ __global__ void __launch_bounds__(WG) k_gemv_t_partial(Batch MT, mw::CPtr v, mw:
 template <int NL>
 __global__ void __launch_bounds__(WG) k_sum_partials(mw::CPtr part, int J, int N, mw::CPtr base, int has_base, int sign, mw::Ptr out)
 {
-  const int n = blockIdx.x * WG + threadIdx.x;
-  if(n >= N)
-    return;
+  // SP_G lanes share one n (J sequential adds in one lane were a J-long dependent chain on N lanes
+  // only): lane (i, g) adds blocks g, g + SP_G, ... and the SP_G partial sums meet in LDS.
+  // workgroup = SP_N consecutive n (coalesced loads along n) x SP_G groups
+  constexpr int SP_G = 8, SP_N = WG / SP_G;
+  const int i = threadIdx.x % SP_N, g = threadIdx.x / SP_N;
+  const int n = blockIdx.x * SP_N + i;
+  __shared__ Mw<NL> sm[WG];
   Acc<NL> acc = mw::acc_zero<NL>();
-  for(int j = 0; j < J; ++j)
-    mw::acc_add(acc, mw::load<NL>(part, (size_t)j * N + n), sign < 0 ? 1u : 0u);
+  if(n < N)
+    for(int j = g; j < J; j += SP_G)
+      mw::acc_add(acc, mw::load<NL>(part, (size_t)j * N + n), sign < 0 ? 1u : 0u);
+  sm[threadIdx.x] = mw::acc_result(acc);
+  __syncthreads();
+  if(g != 0 || n >= N)
+    return;
+  Acc<NL> tot = mw::acc_zero<NL>();
+  for(int gg = 0; gg < SP_G; ++gg)
+    mw::acc_add(tot, sm[gg * SP_N + i]);
   if(has_base)
-    mw::acc_add(acc, mw::load<NL>(base, n));
-  mw::store<NL>(out, n, mw::acc_result(acc));
+    mw::acc_add(tot, mw::load<NL>(base, n));
+  mw::store<NL>(out, n, mw::acc_result(tot));
 }
+constexpr int SP_ROWS = WG / 8; // values of n per workgroup of k_sum_partials
 // out_j[p] += sign * sum_n MT_j(n,p) v[n]: dx += P dy (solve_schur_complement_equation.
 // cxx:69-74) and d -= B y (compute_dual_residues_and_error.cxx:52-54).  A workgroup
 // owns 4 values of p; 64 lanes stride over n (coalesced column reads) and meet in an

@@ -1180,12 +1180,12 @@ private:
     launch(k_gemv_t_partial<NL, SQUARE>, dim3(cdiv(N_, WG), Jl_), dim3(WG), stream_, btB(MT), v.cptr(), part.ptr(), d_blk_.p, N_);
     if(world_ == 1)
       {
-        launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part.cptr(), Jl_, N_, base ? base->cptr() : out.cptr(),
+        launch(k_sum_partials<NL>, dim3(cdiv(N_, SP_ROWS)), dim3(WG), stream_, part.cptr(), Jl_, N_, base ? base->cptr() : out.cptr(),
                base ? 1 : 0, sign, out.ptr());
         return;
       }
     // local sum, cross-rank sum, then base + sign*sum
-    launch(k_sum_partials<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, part.cptr(), Jl_, N_, out.cptr(), 0, 1, out.ptr());
+    launch(k_sum_partials<NL>, dim3(cdiv(N_, SP_ROWS)), dim3(WG), stream_, part.cptr(), Jl_, N_, out.cptr(), 0, 1, out.ptr());
     allreduce_vec_sum(out, N_);
     launch(k_base_plus_signed<NL>, dim3(cdiv(N_, WG)), dim3(WG), stream_, out.ptr(), base ? base->cptr() : out.cptr(), base ? 1 : 0, sign, N_);
   }
