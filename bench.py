@@ -303,12 +303,14 @@ def main():
         from sdpb_amd.solver import copy_bandwidth_gbs
         copy_gbs = copy_bandwidth_gbs(1 << 30, 5, lib_path=args.lib)
         out = {
-            "metric": "interior-point iterations/sec at --precision 512",
+            "metric": f"interior-point iterations/sec at --precision {precision}",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": f"mw{32 * nl} (fixed-width multi-word float, {nl}x32-bit limbs; Q syrk in {32 * (nl - 2)}-bit fixed point)",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synthetic 3d-Ising mixed-correlator SDP (SURVEY.md §8d), "
+            "config": {"workload": f"{args.workload}: synthetic "
+                                   + ("3d-Ising mixed-correlator" if args.workload == "C4" else "stress" if args.workload.startswith("C5")
+                                      else "bootstrap-shaped") + " SDP (SURVEY.md §8d), "
                                    f"J={sdp.J}, N={sdp.N}, P_tot={sdp.P_total}, --precision {precision}"
                                    + ("" if args.scale == 1.0 else f" [scaled x{args.scale}]"),
                        "parallelism": f"blocks sharded over {world} GPU(s); Q' summed by integer all-reduce",

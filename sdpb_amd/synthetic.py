@@ -111,6 +111,8 @@ CONFIGS = {
     "C3": dict(dims=[1] * 600, num_points=[30] * 600, N=100, precision=512, seed=3),
     "C4": dict(dims=[2] * 200 + [1] * 400, num_points=[40] * 600, N=1000, precision=512, seed=4),
     "C5": dict(dims=[6] * 8192, num_points=[2] * 8192, N=2048, precision=1024, seed=5),
+    # one GPU's share of C5 under 8-way block sharding, with the full N: what a rank of the 8-GPU job holds
+    "C5slice": dict(dims=[6] * 1024, num_points=[2] * 1024, N=2048, precision=1024, seed=5),
 }
 
 
