@@ -48,3 +48,20 @@ def test_oracle_matches_reference_golden(name, limit):
 @pytest.mark.parametrize("name,limit", SLOW)
 def test_oracle_matches_reference_golden_full(name, limit):
     _replay(name, limit)
+
+
+def test_oracle_is_bit_identical_for_any_thread_count():
+    """The OpenMP loops only split independent outputs and keep every sum's order."""
+    sdp, meta, iters, _ = parity.load_case("dfibo")
+    traces = []
+    for threads in (1, 3, 8):
+        o = Oracle(sdp, meta["precision"], meta["params"], param_prec=64, threads=threads)
+        assert o.threads == threads
+        t = []
+        for _ in range(3):
+            assert not o.iterate()
+            t.append(o.scalars())
+        t.append(o.array("dy"))
+        traces.append(t)
+        o.close()
+    assert traces[0] == traces[1] == traces[2]
