@@ -360,7 +360,12 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
 // Tile helper shared by the panel kernels: a workgroup owns TR = 8 rows x PB columns;
 // lane t -> (row t % 8, column t / 8), so consecutive lanes read consecutive rows.
 constexpr int TR = WG / PB;
-constexpr int TRSM_KC = PB < 8 ? PB : 8; // columns per LDS-staged operand chunk of the panel kernels
+// 4 columns per chunk: 31 KB of LDS per workgroup = 5 workgroups per CU; measured on C4 (P = L^{-1}B stage):
+// KC 16: 41.5 ms, 8: 37.5 ms, 4: 35.6 ms, 2: 35.9 ms
+#ifndef SDPB_TRSM_KC
+#define SDPB_TRSM_KC 4
+#endif
+constexpr int TRSM_KC = PB < SDPB_TRSM_KC ? PB : SDPB_TRSM_KC; // columns per LDS-staged operand chunk of the panel kernels
 
 // Cholesky panel solve: A(r, panel p) := A(r, panel p) * Li_pp^T for the rows below the
 // diagonal block, and zero the part of the panel above it.   grid = (row tiles, batch)
