@@ -158,9 +158,29 @@ constexpr int CI_E = 3;                                 // off-diagonal elements
 constexpr int CI_GPR = (PB / 2 + CI_E - 1) / CI_E;      // lanes per round
 static_assert(PB % 2 == 0 && PB <= 64 && (PB - 1) * CI_GPR <= CI_D0, "k_chol_inv_lds: element-to-lane mapping");
 
-// limb-major LDS image of a packed triangle (conflict-free for consecutive elements)
-template <int NL> MW_HD Mw<NL> ci_ld(const uint32_t *s, int idx) { return smem_ld<NL, CI_NPK>(s, idx); }
-template <int NL> MW_HD void ci_st(uint32_t *s, int idx, const Mw<NL> &v) { smem_st<NL, CI_NPK>(s, idx, v); }
+// limb-major LDS image of a packed triangle (conflict-free for consecutive elements); sign and
+// exponent share one word (NL + 1 planes), which brings the two triangles of a 32 x 32 block at
+// 576 bits under half of the CU's LDS: two workgroups per CU in the batched launches
+constexpr int CI_PLANES_EXTRA = 1;
+template <int NL> MW_HD Mw<NL> ci_ld(const uint32_t *s, int idx)
+{
+  Mw<NL> v;
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    v.m[l] = s[l * CI_NPK + idx];
+  const uint32_t hd = s[NL * CI_NPK + idx];
+  v.neg = hd >> 31;
+  v.e = hd ? (int32_t)((hd & 0x7fffffffu) - mw::EBIAS) : mw::EZERO;
+  return v;
+}
+template <int NL> MW_HD void ci_st(uint32_t *s, int idx, const Mw<NL> &v)
+{
+  const bool z = v.e == mw::EZERO;
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    s[l * CI_NPK + idx] = z ? 0u : v.m[l];
+  s[NL * CI_NPK + idx] = z ? 0u : ((v.neg << 31) | (uint32_t)(v.e + (int32_t)mw::EBIAS));
+}
 
 // One element (r,c), r > c, of a diagonal block, or a diagonal element (r == c).
 template <int NL> struct CiElem
@@ -241,7 +261,7 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
   if(k0 >= d.rows)
     return;
   const int n = d.rows - k0 < PB ? d.rows - k0 : PB;
-  __shared__ uint32_t sL[(NL + 2) * CI_NPK], sX[(NL + 2) * CI_NPK];
+  __shared__ uint32_t sL[(NL + CI_PLANES_EXTRA) * CI_NPK], sX[(NL + CI_PLANES_EXTRA) * CI_NPK];
   __shared__ uint32_t s_inv[NL + 2];
   __shared__ int s_fail;
   // the lane's elements, as separate objects so that the accumulators stay in registers
@@ -2363,7 +2383,12 @@ __device__ inline int sturm_count_f64(const double *a, const double *b2, int n, 
 // of TRI_T lanes per matrix.  D = diagonal, E[1..n) = off-diagonal of the tridiagonal
 // matrix.  Row dot products are split over teams of lanes and meet in LDS so that the
 // dependent chain per Householder step stays short.
-constexpr int TRI_T = 256;
+// 128 lanes per matrix: with 242 VGPRs a 256-lane workgroup leaves room for 512 of C4's 1200 matrices at a time
+// (2.3 rounds of a latency-bound kernel), 128 lanes for 1024 (1.2 rounds): step lengths 14.2 -> 10.7 ms (64: 13.3)
+#ifndef SDPB_TRI_T
+#define SDPB_TRI_T 128
+#endif
+constexpr int TRI_T = SDPB_TRI_T;
 template <int NL> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
 {
   const int t = threadIdx.x;
