@@ -66,10 +66,30 @@ struct alignas(16) Quad
 {
   uint32_t x, y, z, w;
 };
+// four 16-byte nontemporal loads in flight per lane, one workgroup per 16 KiB (no grid-stride loop): 6.2 TB/s on
+// MI355X, against 4.7 TB/s for 8192 workgroups striding over the buffer (scratch measurement, round 2)
 __global__ void __launch_bounds__(256) k_copy16(const Quad *src, Quad *dst, size_t n)
 {
-  for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    dst[i] = src[i];
+#if defined(__HIPCC__)
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  const v4 *s = reinterpret_cast<const v4 *>(src);
+  v4 *d = reinterpret_cast<v4 *>(dst);
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  v4 v[4];
+#pragma unroll
+  for(int u = 0; u < 4; ++u)
+    if(base + (size_t)u * 256 < n)
+      v[u] = __builtin_nontemporal_load(s + base + (size_t)u * 256);
+#pragma unroll
+  for(int u = 0; u < 4; ++u)
+    if(base + (size_t)u * 256 < n)
+      __builtin_nontemporal_store(v[u], d + base + (size_t)u * 256);
+#else // CPU emulation build (tests): same index map, plain copies
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  for(int u = 0; u < 4; ++u)
+    if(base + (size_t)u * 256 < n)
+      dst[base + (size_t)u * 256] = src[base + (size_t)u * 256];
+#endif
 }
 
 extern "C" {
@@ -500,7 +520,7 @@ int sdpb_hip_copy_bandwidth(size_t bytes, int reps, double *gb_per_s)
       for(int r = 0; r < std::max(reps, 1) + 1; ++r)
         {
           HIP_CHECK(hipEventRecord(e0, nullptr));
-          hipLaunchKernelGGL(k_copy16, dim3(256 * 32), dim3(256), 0, nullptr, (const Quad *)src.p, dst.p, n);
+          hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, nullptr, (const Quad *)src.p, dst.p, n);
           HIP_CHECK(hipEventRecord(e1, nullptr));
           HIP_CHECK(hipEventSynchronize(e1));
           float ms = 0;

@@ -1285,7 +1285,7 @@ private:
       }
       const size_t cnt = Ptot_ * (size_t)N_;
       if(cnt)
-        launch(k_normalize_fx<NL, FX>, dim3(std::min<unsigned>(cdiv(cnt, WG), 8192)), dim3(WG), stream_, PT_.cptr(), cnt, N_,
+        launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT_.cptr(), cnt, N_, // one element per lane: streams at HBM rate
                invnorms_.cptr(), fx_.p, fx_stride_);
       const unsigned tiles = cdiv(N_, 16);
       if(cnt)
