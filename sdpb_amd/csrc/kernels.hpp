@@ -486,6 +486,76 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
     mat_st<NL>(A, d, b0 + i, b0 + j, mw::acc_result(acc));
 }
 
+// The two strip steps of the look-ahead Cholesky(Q) sit between consecutive diagonal blocks on the
+// critical path of the iteration, and each of their outputs is a PB-term dot product: eight lanes
+// per output (four terms each, partial sums through LDS) instead of one lane running PB dependent
+// products — 62 + 47 us -> ~2 x 20 us per panel.  Single matrix (A.d[0]).
+// (a) the PB rows below diagonal block p:  A(r, panel p) := A(r, panel p) Li_pp^T; one workgroup per row
+//     (it also zeroes row blockIdx.x of the panel above the diagonal block, as k_chol_panel_solve does)
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_strip_solve(Batch A, Batch Li, int p)
+{
+  static_assert(WG % PB == 0 || PB > WG, "lanes per output");
+  constexpr int SEG = PB <= WG ? WG / PB : 1;
+  const MatDesc d = A.d[0], di = Li.d[0];
+  const int k0 = PB * p, t = threadIdx.x;
+  if(k0 >= d.rows)
+    return;
+  const int nb = d.rows - k0 < PB ? d.rows - k0 : PB;
+  const int j = t / SEG, s = t % SEG;
+  const int r = k0 + nb + (int)blockIdx.x;
+  const bool ok = r < d.rows && j < nb;
+  __shared__ Mw<NL> part[WG];
+  Acc<NL> acc = mw::acc_zero<NL>();
+  if(ok)
+    for(int k = s; k <= j; k += SEG)
+      mw::acc_fma(acc, mat_ld<NL>(A, d, r, k0 + k), mat_ld<NL>(Li, di, k0 + j, k0 + k));
+  part[t] = mw::acc_result(acc);
+  __syncthreads(); // every read of row r precedes the writes below
+  if(ok && s == 0)
+    {
+      Acc<NL> sum = mw::acc_zero<NL>();
+      for(int g = 0; g < SEG; ++g)
+        mw::acc_add(sum, part[t + g]);
+      mat_st<NL>(A, d, r, k0 + j, mw::acc_result(sum));
+    }
+  const int ru = (int)blockIdx.x;
+  if(ru < k0 && t < nb)
+    mat_st<NL>(A, d, ru, k0 + t, mw::zero<NL>());
+}
+// (b) the leading PB x PB block of the trailing update: A(i,j) -= sum_k A(i, k0+k) A(j, k0+k), i >= j;
+//     WG / SEG outputs per workgroup in packed lower-triangle order
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_strip_update(Batch A, int p)
+{
+  constexpr int SEG = PB <= WG ? WG / PB : 1, OUT = WG / SEG;
+  const MatDesc d = A.d[0];
+  const int k0 = PB * p, t = threadIdx.x;
+  if(k0 >= d.rows)
+    return;
+  const int nb = d.rows - k0 < PB ? d.rows - k0 : PB;
+  const int b0 = k0 + nb, M = d.rows - b0 < PB ? d.rows - b0 : PB;
+  const int o = (int)blockIdx.x * OUT + t / SEG, s = t % SEG;
+  int i = 0;
+  while((i + 1) * (i + 2) / 2 <= o)
+    ++i;
+  const int j = o - i * (i + 1) / 2;
+  const bool ok = i < M;
+  __shared__ Mw<NL> part[WG];
+  Acc<NL> acc = mw::acc_zero<NL>();
+  if(ok)
+    for(int k = s; k < nb; k += SEG)
+      mw::acc_fms(acc, mat_ld<NL>(A, d, b0 + i, k0 + k), mat_ld<NL>(A, d, b0 + j, k0 + k));
+  part[t] = mw::acc_result(acc);
+  __syncthreads();
+  if(ok && s == 0)
+    {
+      Acc<NL> sum = mw::acc_zero<NL>();
+      mw::acc_add(sum, mat_ld<NL>(A, d, b0 + i, b0 + j));
+      for(int g = 0; g < SEG; ++g)
+        mw::acc_add(sum, part[t + g]);
+      mat_st<NL>(A, d, b0 + i, b0 + j, mw::acc_result(sum));
+    }
+}
+
 // X := X L^{-T}, panel p (forward over panels):
 //   T = X(:,panel p) - X(:,cols < k0) L(panel p, cols < k0)^T ;  X(:,panel p) = T Li_pp^T
 // One lane per (row, column of the panel); rows are the independent right-hand sides

@@ -1032,8 +1032,8 @@ private:
         const int ntile = (int)(tiles * (tiles + 1) / 2);
         const int strip_rows = below > 0 ? std::min(row_tiles, STRIP_ROW_TILES) : 0;
         const int strip_tiles = std::min(ntile, STRIP_TILES);
-        if(strip_rows > 0)
-          launch(k_chol_panel_solve<NL>, dim3(strip_rows, 1), dim3(WG), st, A, Li, p, 0);
+        if(strip_rows > 0) // the PB rows below the diagonal block (+ zeroing of rows [0, PB) above it)
+          launch(k_chol_strip_solve<NL>, dim3(std::min(strip_rows * TR, std::max(below, above))), dim3(WG), st, A, Li, p);
         HIP_CHECK(hipEventRecord(ev_la_strip_, st));
         HIP_CHECK(hipStreamWaitEvent(st2, ev_la_strip_, 0));
         if(row_tiles > strip_rows)
@@ -1041,8 +1041,8 @@ private:
         if(ntile > strip_tiles)
           launch(k_chol_syrk_down<NL>, dim3(ntile - strip_tiles, 1), dim3(WG), st2, A, p, strip_tiles);
         HIP_CHECK(hipEventRecord(ev_la_bulk_, st2));
-        if(strip_tiles > 0)
-          launch(k_chol_syrk_down<NL>, dim3(strip_tiles, 1), dim3(WG), st, A, p, 0);
+        if(strip_tiles > 0) // leading PB x PB block of the trailing update
+          launch(k_chol_strip_update<NL>, dim3(cdiv((size_t)PB * (PB + 1) / 2, WG / (PB <= WG ? WG / PB : 1))), dim3(WG), st, A, p);
         if(p + 1 < panels)
           launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, p + 1, fail); // overlaps the bulk of step p
         HIP_CHECK(hipStreamWaitEvent(st, ev_la_bulk_, 0));

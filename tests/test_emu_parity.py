@@ -89,3 +89,19 @@ def test_emulated_library_matches_oracle_on_dim6_blocks():
         bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=256)
         assert not bad, (it + 1, bad)
     s.close()
+
+
+def test_emulated_library_beyond_one_panel_of_Q():
+    """N = 40 > PB = 32: two panels of Cholesky(Q) with the look-ahead schedule and its strip kernels
+    (eight lanes per output), two panels of the Q solves — index arithmetic against the oracle."""
+    from oracle.oracle import Oracle
+    from sdpb_amd.synthetic import make_sdp
+    sdp = make_sdp([1] * 5, [18] * 5, 40, 512, seed=11)
+    s = SDPSolver(sdp, 512, parity.DEFAULT_PARAMS, lib_path=libs.emu_lib())
+    o = Oracle(sdp, 512, parity.DEFAULT_PARAMS, param_prec=0)
+    for it in range(3):
+        assert not s.iterate() and not o.iterate()
+        bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=256)
+        assert not bad, (it + 1, bad)
+    s.close()
+    o.close()
