@@ -880,7 +880,7 @@ private:
     launch(k_combine_slots<NL>, dim3(1), dim3(64), stream_, (const uint32_t *)xgather_.p, world_, (int)R_COUNT, ops, resbuf_.p);
   }
   // THE synchronisation point: one copy of the result block, then the host decides.
-  void fetch()
+  void fetch(unsigned max_stage = FAIL_Q)
   {
     uint32_t h[RES_WORDS];
     HIP_CHECK(hipMemcpyAsync(h, resbuf_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
@@ -896,13 +896,13 @@ private:
       }
     for(int k = 0; k < X_EXTRA; ++k)
       xw_host_[k] = h[(size_t)(NL + 1) * R_COUNT + k];
-    throw_if_failed();
+    throw_if_failed(max_stage);
   }
   // the reference's RUNTIME_ERRORs, from the smallest failure tag of all ranks
-  void throw_if_failed()
+  void throw_if_failed(unsigned max_stage)
   {
     const uint32_t tag = xw_host_[XW_FAIL];
-    if(tag == 0xffffffffu)
+    if(tag == 0xffffffffu || (tag >> 27) > max_stage)
       return;
     // leave the streams quiet before unwinding (the side streams may still be busy)
     (void)hipStreamSynchronize(stream_q_);
@@ -1626,7 +1626,6 @@ private:
   {
     upload_scalar(S_MU, mu_);
     queue_R_error();
-    initialize_schur_complement_solver();
     {
       Timer t(this, "computeSearchDirection(betaPredictor)");
       const M beta_predictor = feasible ? mw::zero<NL>() : infeasible_centering_parameter_; // predictor_centering_parameter.cxx:4-9
@@ -1700,14 +1699,21 @@ public:
     queue_objectives();
     factor_X_and_Y();
     compute_bilinear_pairings();
+    // The Schur complement solver (step.cxx:117-127) needs only X and Y, so it is queued BEFORE the
+    // residues and the termination test: Cholesky(Q), the dependent chain that follows the syrk on
+    // the side streams, then runs beside the residues as well as beside the predictor's
+    // Q-independent part.  On the (last) iteration that terminates here the work is discarded — S, P, Q
+    // are scratch — and a failure in it is not raised (the reference would not have computed it).
+    initialize_schur_complement_solver();
     compute_dual_residues_and_error();
     compute_primal_residues_P();
     compute_primal_residue_p();
     queue_minus_XY_and_trace();
     exchange({{R_CX, X_SUM}, {R_DERR, X_MAX}, {R_PERR_P, X_MAX}, {R_TRACE, X_SUM}});
-    fetch(); // raises Cholesky failures of X and Y
+    fetch(FAIL_Y); // raises Cholesky failures of X and Y only
     if(xw_host_[XW_OR])
       {
+        join_cholesky_Q();
         terminate_reason_ = SIGTERM_Received; // run.cxx:332-355: any rank, graceful exit
         return true;
       }
@@ -1720,11 +1726,15 @@ public:
     primal_error_p_ = res_host_[R_PERR_p];
     bool feasible = false;
     if(compute_feasible_and_termination(feasible, xw_host_[XW_STOP] != 0))
-      return true;
+      {
+        join_cholesky_Q();
+        return true;
+      }
     Timer t(this, "step");
     mu_ = mw::div(mw::neg(res_host_[R_TRACE]), mw::from_u32<NL>((uint32_t)total_psd_rows_));
-    if(mw::gt(mu_, max_complementarity_)) // step.cxx:145-153
+    if(mw::gt(mu_, max_complementarity_)) // step.cxx:145-153 (after the Schur complement solver, as here)
       {
+        join_cholesky_Q();
         terminate_reason_ = MaxComplementarityExceeded;
         return true;
       }
