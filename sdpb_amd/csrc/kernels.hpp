@@ -932,12 +932,19 @@ __global__ void __launch_bounds__(WG) k_build_bases_block(Batch bases, Batch E, 
 // the pairing tiles, lower triangle computed and mirrored (MakeSymmetric LOWER :121).
 // AX, AY batches are indexed 2j+parity; S by j.
 template <int NL>
-__global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Batch S, const BlockDesc *blk)
+__global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Batch S, const BlockDesc *blk, int strips)
 {
-  const int j = blockIdx.y;
+  // XCD-aware order (1-D grid of 8 * ceil(count / 8) * strips workgroups): workgroup b runs on XCD b % 8,
+  // and all `strips` workgroups of a block go to the SAME XCD (blocks j = xcd, xcd + 8, ...), so the
+  // block's pairing tiles — read 16 times over by the (r,s)-pair sub-blocks of S_j — are fetched into
+  // one L2 once instead of into all eight (the kernel is bound by that traffic, not by its products).
+  const int xcd = (int)(blockIdx.x % 8), slot = (int)(blockIdx.x / 8);
+  const int j = (slot / strips) * 8 + xcd, strip = slot % strips;
+  if(j >= S.count)
+    return;
   const MatDesc ds = S.d[j];
   const int P = ds.rows, K = blk[j].K;
-  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t idx = (size_t)strip * WG + threadIdx.x;
   if(idx >= (size_t)P * P)
     return;
   const int R = (int)(idx % P), C = (int)(idx / P);
@@ -990,13 +997,28 @@ __global__ void __launch_bounds__(WG) k_dual_residues(Batch AY, mw::CPtr c, mw::
 
 // result = sum_p a[p] A_p (+/- addend)   (constraint_matrix_weighted_sum.cxx:14-66)
 // out batch is indexed 2j+parity.  addend_sign: 0 none, +1 add, -1 subtract.
+// The scaled samples t(pair, j, k) = q_j(x_k) a[pair, k] are rounded products that every row i of the
+// output shares, so they are formed once by k_scale_bases (into `scaled`, K x (pairs rs) per parity,
+// k fastest) instead of rs times over inside the sum: same values, same order, half the products.
+template <int NL> __global__ void __launch_bounds__(WG) k_scale_bases(Batch bases, mw::CPtr a, Batch scaled, const BlockDesc *blk)
+{
+  const int q = blockIdx.y;
+  const BlockDesc bl = blk[q >> 1];
+  const MatDesc dbs = bases.d[q], dsc = scaled.d[q];
+  const int rs = bl.rows[q & 1], K = bl.K;
+  const int idx = blockIdx.x * WG + threadIdx.x;
+  if(idx >= dsc.rows * dsc.cols)
+    return;
+  const int k = idx % K, col = idx / K, pair = col / rs, jj = col % rs;
+  mat_st<NL>(scaled, dsc, k, col, mw::mul(mat_ld<NL>(bases, dbs, jj, k), mw::load<NL>(a, (size_t)bl.voff + (size_t)pair * K + k)));
+}
 template <int NL>
-__global__ void __launch_bounds__(WG) k_constraint_weighted_sum(Batch bases, mw::CPtr a, Batch out, Batch addend,
+__global__ void __launch_bounds__(WG) k_constraint_weighted_sum(Batch bases, Batch scaled, Batch out, Batch addend,
                                                                 int addend_sign, const BlockDesc *blk)
 {
   const int q = blockIdx.y;
   const BlockDesc bl = blk[q >> 1];
-  const MatDesc dout = out.d[q], dbs = bases.d[q];
+  const MatDesc dout = out.d[q], dbs = bases.d[q], dsc = scaled.d[q];
   const int n = dout.rows, rs = bl.rows[q & 1];
   const int idx = blockIdx.x * WG + threadIdx.x;
   if(idx >= n * n)
@@ -1004,13 +1026,10 @@ __global__ void __launch_bounds__(WG) k_constraint_weighted_sum(Batch bases, mw:
   const int I = idx % n, Jc = idx / n;
   const int bi = I / rs, i = I % rs, bj = Jc / rs, jj = Jc % rs;
   const int hi = bi > bj ? bi : bj, lo = bi > bj ? bj : bi;
-  const size_t voff = (size_t)bl.voff + (size_t)(hi * (hi + 1) / 2 + lo) * bl.K;
+  const int col = (hi * (hi + 1) / 2 + lo) * rs + jj;
   Acc<NL> sum = mw::acc_zero<NL>();
   for(int k = 0; k < bl.K; ++k)
-    {
-      const Mw<NL> t = mw::mul(mat_ld<NL>(bases, dbs, jj, k), mw::load<NL>(a, voff + k));
-      mw::acc_fma(sum, mat_ld<NL>(bases, dbs, i, k), t);
-    }
+    mw::acc_fma(sum, mat_ld<NL>(bases, dbs, i, k), mat_ld<NL>(scaled, dsc, k, col));
   Mw<NL> acc = mw::acc_result(sum);
   if(hi != lo)
     acc = mw::mul_2exp(acc, -1);
@@ -1060,8 +1079,13 @@ __global__ void __launch_bounds__(WG)
 // is what this latency-bound kernel costs: 3.0 -> 0.4 ms per launch.  grid (max pairs, blocks).
 template <int NL>
 __global__ void __launch_bounds__(WG)
-  k_schur_rhs2(Batch bases, Batch Z, mw::CPtr dres, mw::Ptr dx, const BlockDesc *blk)
+  k_schur_rhs2(Batch basesT, Batch Z, mw::CPtr dres, mw::Ptr dx, const BlockDesc *blk)
 {
+  // basesT is the K x rs transpose (sample index fastest): the lanes of a group, which differ in k,
+  // read consecutive words.  Z is symmetric to the bit (symmetrize() ran just before), so the
+  // broadcast operand is read as Z(cb rs + l, rb rs + i): consecutive l are consecutive words.
+  // With the rs x K layout and Z along a row both loads touched one cache line per word and the
+  // kernel was bound by 4.4 GB of L2 misses for 0.15 GB of data.
   const int j = blockIdx.y, t = threadIdx.x;
   const BlockDesc bl = blk[j];
   const int pair = blockIdx.x;
@@ -1082,13 +1106,13 @@ __global__ void __launch_bounds__(WG)
         for(int b = 0; b < 2; ++b)
           {
             const int rs = bl.rows[b];
-            const MatDesc dz = Z.d[2 * j + b], dbs = bases.d[2 * j + b];
+            const MatDesc dz = Z.d[2 * j + b], dbt = basesT.d[2 * j + b];
             for(int i = g; i < rs; i += G)
               {
                 Acc<NL> zq = mw::acc_zero<NL>();
                 for(int l = 0; l < rs; ++l)
-                  mw::acc_fma(zq, mat_ld<NL>(Z, dz, rb * rs + i, cb * rs + l), mat_ld<NL>(bases, dbs, l, k));
-                mw::acc_fma(colsum, mw::acc_result(zq), mat_ld<NL>(bases, dbs, i, k));
+                  mw::acc_fma(zq, mat_ld<NL>(Z, dz, cb * rs + l, rb * rs + i), mat_ld<NL>(basesT, dbt, k, l));
+                mw::acc_fma(colsum, mw::acc_result(zq), mat_ld<NL>(basesT, dbt, k, i));
               }
           }
       part[t] = mw::acc_result(colsum);

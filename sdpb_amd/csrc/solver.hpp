@@ -243,17 +243,18 @@ template <int NL> class Solver : public SolverBase
   // ---- descriptors -----------------------------------------------------------
   DevBuf<BlockDesc> d_blk_;
   DevBuf<MatDesc> d_Et_;
-  DevBuf<MatDesc> d_psd_, d_bases_, d_E_, d_pair_, d_schur_, d_bt_, d_vecP_, d_vecn_, d_Q_, d_vecQ_;
+  DevBuf<MatDesc> d_basesT_, d_scaled_, d_psd_, d_bases_, d_E_, d_pair_, d_schur_, d_bt_, d_vecP_, d_vecn_, d_Q_, d_vecQ_;
   std::vector<MatDesc> h_Et_;
-  std::vector<MatDesc> h_psd_, h_bases_, h_E_, h_pair_, h_schur_, h_bt_, h_vecP_, h_vecn_;
+  std::vector<MatDesc> h_basesT_, h_scaled_, h_psd_, h_bases_, h_E_, h_pair_, h_schur_, h_bt_, h_vecP_, h_vecn_;
   // blocked Cholesky(Q): per panel descriptors
   DevBuf<MatDesc> d_qdiag_, d_rowP_; // diagonal blocks of Q; dx as 1 x P row vectors
   int q_nb_ = 0, q_panels_ = 0;
   int max_n_ = 0, max_q_ = 0, max_P_ = 0, max_pairs_ = 1;
+  size_t max_scaled_ = 0;
 
   // ---- device arrays ---------------------------------------------------------
   DevArray X_, Y_, Xc_, Yc_, dX_, dY_, PR_, mXY_, R_, Z_, W_;
-  DevArray bases_, E_, Et_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
+  DevArray basesT_, scaled_, bases_, E_, Et_, T_, YQ_, AX_, AY_, S_, BT_, PT_;
   DevArray c_, x_, dx_, dres_, invdS_, invdX_, invdY_, eigD_, eigE_, eigD2_, eigE2_, cmby_;
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray part2_; // partial sums of the column norms (the Q chain may run beside the predictor, which uses part_)
@@ -433,7 +434,7 @@ private:
   // ==========================================================================
   void build_layout()
   {
-    size_t off_psd = 0, off_bases = 0, off_E = 0, off_pair = 0, off_schur = 0, off_bt = 0, off_vecn = 0;
+    size_t off_scaled = 0, off_psd = 0, off_bases = 0, off_E = 0, off_pair = 0, off_schur = 0, off_bt = 0, off_vecn = 0;
     for(int j = 0; j < J_; ++j)
       {
         const int m = dims_[j], K = npts_[j];
@@ -461,6 +462,11 @@ private:
             h_psd_.push_back(MatDesc{off_psd, n, n, n, K});
             h_vecn_.push_back(MatDesc{off_vecn, n, 1, n, K});
             h_bases_.push_back(MatDesc{off_bases, bd.rows[b], K, bd.rows[b], K});
+            h_basesT_.push_back(MatDesc{off_bases, K, bd.rows[b], K, K});
+            const int pr = m * (m + 1) / 2;
+            h_scaled_.push_back(MatDesc{off_scaled, K, pr * bd.rows[b], K, K});
+            off_scaled += (size_t)K * pr * bd.rows[b];
+            max_scaled_ = std::max(max_scaled_, (size_t)K * pr * bd.rows[b]);
             h_E_.push_back(MatDesc{off_E, n, q, n, K});
             h_Et_.push_back(MatDesc{off_E, q, n, q, K});
             h_pair_.push_back(MatDesc{off_pair, q, q, q, K});
@@ -489,6 +495,8 @@ private:
     d_psd_.upload(h_psd_);
     d_vecn_.upload(h_vecn_);
     d_bases_.upload(h_bases_);
+    d_basesT_.upload(h_basesT_);
+    d_scaled_.upload(h_scaled_);
     d_E_.upload(h_E_);
     d_Et_.upload(h_Et_);
     d_pair_.upload(h_pair_);
@@ -518,6 +526,8 @@ private:
     for(DevArray *a : {&X_, &Y_, &Xc_, &Yc_, &dX_, &dY_, &PR_, &mXY_, &R_, &Z_, &W_, &LiX_, &LiY_})
       a->alloc(off_psd, NL);
     bases_.alloc(off_bases, NL);
+    basesT_.alloc(off_bases, NL);
+    scaled_.alloc(off_scaled, NL);
     for(DevArray *a : {&E_, &Et_, &T_, &YQ_})
       a->alloc(off_E, NL);
     AX_.alloc(off_pair, NL);
@@ -596,6 +606,8 @@ private:
   Batch psd(const DevArray &a) const { return Batch{a.ptr(), d_psd_.p, 2 * Jl_}; }
   Batch vecn(const DevArray &a) const { return Batch{a.ptr(), d_vecn_.p, 2 * Jl_}; }
   Batch basesB() const { return Batch{bases_.ptr(), d_bases_.p, 2 * Jl_}; }
+  Batch basesTB() const { return Batch{basesT_.ptr(), d_basesT_.p, 2 * Jl_}; }
+  Batch scaledB() const { return Batch{scaled_.ptr(), d_scaled_.p, 2 * Jl_}; }
   Batch eB(const DevArray &a) const { return Batch{a.ptr(), d_E_.p, 2 * Jl_}; }
   Batch etB(const DevArray &a) const { return Batch{a.ptr(), d_Et_.p, 2 * Jl_}; }
   Batch pairB(const DevArray &a) const { return Batch{a.ptr(), d_pair_.p, 2 * Jl_}; }
@@ -795,6 +807,7 @@ public:
           for(int k = 0; k < bd.K; ++k)
             cm[(size_t)k * rs + r] = v[(size_t)r * bd.K + k];
         upload<NL>(bases_, h_bases_[2 * l + b].off, cm);
+        upload<NL>(basesT_, h_basesT_[2 * l + b].off, v); // K x rs, sample index fastest = the row-major input
       }
     // bases_blocks (set_bases_blocks.cxx:3-22) for this block's two parities
     Batch bb = basesB(), ee = eB(E_), et = etB(Et_);
@@ -1115,7 +1128,10 @@ private:
     const unsigned tiles_q = cdiv(max_q_, 16) * cdiv(max_q_, 16);
     launch(k_gemm<NL, false, false>, dim3(cdiv(max_n_, 16) * cdiv(max_q_, 16), 2 * Jl_), dim3(WG), stream_, psd(Y_), eB(E_), eB(YQ_), 0, 0,
            0, eB(YQ_), 0, 0);
-    launch(k_gemm<NL, true, false>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, eB(E_), eB(YQ_), pairB(AY_), 0, 0, 1, pairB(AY_), 0, 0);
+    // E^T comes from the stored transpose: lanes of a tile then read consecutive rows of Et (coalesced)
+    // instead of 16 columns of E a row stride apart, whose 19 limb planes overflow the CU's L1
+    // (3.6 ms -> the same products, same order, same bits).
+    launch(k_gemm<NL, false, false>, dim3(tiles_q, 2 * Jl_), dim3(WG), stream_, etB(Et_), eB(YQ_), pairB(AY_), 0, 0, 1, pairB(AY_), 0, 0);
   }
   // cholesky_decomposition.cxx:5-28 for X and Y (run.cxx:386-387).  The factor of a batch of
   // small matrices is a latency-bound chain of pivots, so Y's factor and A_Y (which needs
@@ -1159,7 +1175,9 @@ private:
   // constraint_matrix_weighted_sum.cxx:14-66 (+ the add/subtract that follows it)
   void constraint_matrix_weighted_sum(const DevArray &a, DevArray &out, const DevArray &addend, int sign)
   {
-    launch(k_constraint_weighted_sum<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, basesB(), a.cptr(),
+    // scaled_ is scratch shared by the calls: they are all queued on the main stream, in order
+    launch(k_scale_bases<NL>, dim3(cdiv(max_scaled_, WG), 2 * Jl_), dim3(WG), stream_, basesB(), a.cptr(), scaledB(), d_blk_.p);
+    launch(k_constraint_weighted_sum<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, basesB(), scaledB(),
            psd(out), psd(addend), sign, d_blk_.p);
   }
   // compute_primal_residues_and_error_P_Ax_X.cxx:5-14
@@ -1234,8 +1252,9 @@ private:
   {
     {
       Timer t(this, "initializeSchurComplementSolver.schur_complement");
-      launch(k_schur_complement<NL>, dim3(cdiv((size_t)max_P_ * max_P_, WG), Jl_), dim3(WG), stream_, pairB(AX_), pairB(AY_), schurB(),
-             d_blk_.p);
+      const unsigned strips = cdiv((size_t)max_P_ * max_P_, WG);
+      launch(k_schur_complement<NL>, dim3(8 * cdiv(Jl_, 8) * strips), dim3(WG), stream_, pairB(AX_), pairB(AY_), schurB(), d_blk_.p,
+             (int)strips);
     }
     {
       // compute_Q.cxx:9-61 : L = chol(S) in place, P^T = B^T L^{-T}
@@ -1467,7 +1486,7 @@ private:
     {
       // dx = -d - Tr(A_p Z) ; dy = p
       Timer t(this, "searchDirection.schur_RHS");
-      launch(k_schur_rhs2<NL>, dim3(max_pairs_, Jl_), dim3(WG), stream_, basesB(), psd(Z_), dres_.cptr(), dx_.ptr(), d_blk_.p);
+      launch(k_schur_rhs2<NL>, dim3(max_pairs_, Jl_), dim3(WG), stream_, basesTB(), psd(Z_), dres_.cptr(), dx_.ptr(), d_blk_.p);
     }
     solve_schur_complement_equation();
     {
