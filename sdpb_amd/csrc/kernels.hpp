@@ -253,8 +253,23 @@ template <int NL> MW_HD void ci_update(CiElem<NL> &el, int k, int n, const uint3
 // CI_D0 + k owns (k,k)) whose step (3) is a single product, and there is no barrier
 // between (3) and the next (1): the next rsqrt starts while the other wavefronts are
 // still busy with their three products per lane.
+// Wavefronts of the dependent chains (the pivot chain of Cholesky(Q), its strip kernels, the Q
+// substitutions) share their SIMDs with whatever the other streams run beside them; s_setprio lets the
+// arbiter issue the chain's instructions first (a lone latency-bound wavefront otherwise waits its turn
+// behind four throughput-bound ones).
+#ifndef SDPB_CHAIN_PRIO
+#define SDPB_CHAIN_PRIO 3
+#endif
+MW_HD void raise_chain_priority()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if(SDPB_CHAIN_PRIO > 0)
+    __builtin_amdgcn_s_setprio(SDPB_CHAIN_PRIO);
+#endif
+}
 template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A, Batch invd, Batch Li, int p, int *fail)
 {
+  raise_chain_priority();
   const int q = blockIdx.x;
   const MatDesc d = A.d[q], dv = invd.d[q], di = Li.d[q];
   const int k0 = PB * p, t = threadIdx.x;
@@ -494,6 +509,7 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
 //     (it also zeroes row blockIdx.x of the panel above the diagonal block, as k_chol_panel_solve does)
 template <int NL> __global__ void __launch_bounds__(WG) k_chol_strip_solve(Batch A, Batch Li, int p)
 {
+  raise_chain_priority();
   static_assert(WG % PB == 0 || PB > WG, "lanes per output");
   constexpr int SEG = PB <= WG ? WG / PB : 1;
   const MatDesc d = A.d[0], di = Li.d[0];
@@ -526,6 +542,7 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_strip_solve(Batch
 //     WG / SEG outputs per workgroup in packed lower-triangle order
 template <int NL> __global__ void __launch_bounds__(WG) k_chol_strip_update(Batch A, int p)
 {
+  raise_chain_priority();
   constexpr int SEG = PB <= WG ? WG / PB : 1, OUT = WG / SEG;
   const MatDesc d = A.d[0];
   const int k0 = PB * p, t = threadIdx.x;
@@ -650,33 +667,91 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
 }
 // X := X L^{-1}, panel p (backward over panels):
 //   T = X(:,panel p) - X(:,cols >= k0+nb) L(rows >= k0+nb, panel p) ;  X(:,panel p) = T Li_pp
+// The mirror image of trsm_rlt_tile: the same workgroup tile, the same limb-major LDS staging of
+// KC-column chunks (an array-of-numbers LDS tile and per-lane loads of Li down a column cost this
+// kernel 1.0 ms per launch on the PSD blocks of C4 against 0.5 ms for its twin), and the same order
+// of the terms as before (k ascending, then j2 ascending), so the results keep their bits.
+template <int NL, int COLS>
+MW_HD void trsm_rln_tile(const Batch &L, const Batch &Li, const Batch &X, const MatDesc &dl, const MatDesc &di, const MatDesc &dx, int k0, int nb,
+                         uint32_t *smem)
+{
+  constexpr int KC = TRSM_KC, ROWS = WG / COLS, SXN = ROWS * KC, SLN = COLS * KC, STN = ROWS * COLS;
+  uint32_t *sx = smem, *sl = sx + (NL + 2) * SXN, *st = sl + (NL + 2) * SLN;
+  if((int)(blockIdx.x * ROWS) >= dx.rows)
+    return;
+  const int n = dl.rows;
+  const int rl = threadIdx.x % ROWS, j = threadIdx.x / ROWS;
+  const int r0 = blockIdx.x * ROWS, r = r0 + rl;
+  const bool ok = r < dx.rows && j < nb;
+  Acc<NL> acc = mw::acc_zero<NL>();
+  if(ok)
+    mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
+  for(int k = k0 + nb; k < n; k += KC)
+    {
+      for(int e = threadIdx.x; e < SXN + SLN; e += WG)
+        {
+          if(e < SXN)
+            {
+              const int kk = e / ROWS, rr = e % ROWS;
+              smem_st<NL, SXN>(sx, e, (r0 + rr < dx.rows && k + kk < n) ? mat_ld<NL>(X, dx, r0 + rr, k + kk) : mw::zero<NL>());
+            }
+          else
+            {
+              const int f = e - SXN, kk = f / COLS, jj = f % COLS;
+              smem_st<NL, SLN>(sl, f, (jj < nb && k + kk < n) ? mat_ld<NL>(L, dl, k + kk, k0 + jj) : mw::zero<NL>());
+            }
+        }
+      __syncthreads();
+      if(ok)
+        {
+#pragma unroll 1
+          for(int kk = 0; kk < KC; ++kk)
+            mw::acc_fms(acc, smem_ld<NL, SXN>(sx, kk * ROWS + rl), smem_ld<NL, SLN>(sl, kk * COLS + j));
+        }
+      __syncthreads();
+    }
+  smem_st<NL, STN>(st, j * ROWS + rl, ok ? mw::acc_result(acc) : mw::zero<NL>());
+  acc = mw::acc_zero<NL>();
+  // X(r, k0+j) = sum_{j2 >= j} T(r, j2) Li(k0+j2, k0+j)
+  for(int c = 0; c < nb; c += KC)
+    {
+      for(int f = threadIdx.x; f < SLN; f += WG)
+        {
+          const int kk = f / COLS, jj = f % COLS;
+          smem_st<NL, SLN>(sl, f, (jj < nb && c + kk < nb && c + kk >= jj) ? mat_ld<NL>(Li, di, k0 + c + kk, k0 + jj) : mw::zero<NL>());
+        }
+      __syncthreads(); // also orders the writes of st before the first read
+      if(ok)
+        {
+#pragma unroll 1
+          for(int kk = 0; kk < KC; ++kk)
+            if(c + kk >= j && c + kk < nb)
+              mw::acc_fma(acc, smem_ld<NL, STN>(st, (c + kk) * ROWS + rl), smem_ld<NL, SLN>(sl, kk * COLS + j));
+        }
+      __syncthreads();
+    }
+  if(ok)
+    mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
+}
 template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rln_panel(Batch L, Batch Li, Batch X, int p)
 {
+  constexpr int KC = TRSM_KC;
   const int q = blockIdx.y;
   const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
-  const int k0 = PB * p, n = dl.rows;
-  if(k0 >= n || (int)(blockIdx.x * TR) >= dx.rows)
+  const int k0 = PB * p;
+  if(k0 >= dl.rows)
     return;
-  const int nb = n - k0 < PB ? n - k0 : PB;
-  const int rl = threadIdx.x % TR, j = threadIdx.x / TR;
-  const int r = blockIdx.x * TR + rl;
-  __shared__ Mw<NL> tile[TR][PB];
-  const bool ok = r < dx.rows && j < nb;
-  if(ok)
+  const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
+  constexpr int MINC = PB < 8 ? PB : 8, NMAX = (WG / MINC + MINC) * KC > (WG / PB + PB) * KC ? (WG / MINC + MINC) * KC : (WG / PB + PB) * KC;
+  __shared__ uint32_t smem[(NL + 2) * (NMAX + WG)];
+  if constexpr(PB >= 32)
     {
-      Acc<NL> acc = mw::acc_zero<NL>();
-      mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
-      for(int k = k0 + nb; k < n; ++k)
-        mw::acc_fms(acc, mat_ld<NL>(X, dx, r, k), mat_ld<NL>(L, dl, k, k0 + j));
-      tile[rl][j] = mw::acc_result(acc);
+      if(nb <= 8)
+        return trsm_rln_tile<NL, 8>(L, Li, X, dl, di, dx, k0, nb, smem);
+      if(nb <= 16)
+        return trsm_rln_tile<NL, 16>(L, Li, X, dl, di, dx, k0, nb, smem);
     }
-  __syncthreads();
-  if(!ok)
-    return;
-  Acc<NL> acc = mw::acc_zero<NL>();
-  for(int j2 = j; j2 < nb; ++j2)
-    mw::acc_fma(acc, tile[rl][j2], mat_ld<NL>(Li, di, k0 + j2, k0 + j));
-  mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
+  trsm_rln_tile<NL, PB>(L, Li, X, dl, di, dx, k0, nb, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -699,10 +774,24 @@ __global__ void __launch_bounds__(WG)
   const int tile = blockIdx.x;
   if(tile >= tiles_i * tiles_j)
     return;
-  const int ti = tile % tiles_i, tj = tile / tiles_i;
-  if(sym && tj > ti)
-    return;
-  const int i = ti * 16 + (threadIdx.x & 15), j = tj * 16 + (threadIdx.x >> 4);
+  int i, j;
+  if(sym)
+    {
+      const int ti = tile % tiles_i, tj = tile / tiles_i;
+      if(tj > ti)
+        return;
+      i = ti * 16 + (threadIdx.x & 15);
+      j = tj * 16 + (threadIdx.x >> 4);
+    }
+  else
+    {
+      // full products: outputs in column-major order, WG consecutive ones per workgroup (a 40 x 40 block
+      // fills 6.25 workgroups instead of nine 16 x 16 tiles of which five are ragged: 89 % instead of
+      // 69 % of the launched lanes hold an output); the grid is still sized in tiles, the surplus exits
+      const int idx = tile * WG + threadIdx.x;
+      i = idx % M;
+      j = idx / M;
+    }
   if(i >= M || j >= Nn || (sym && j > i))
     return;
   Acc<NL> sum = mw::acc_zero<NL>();
@@ -836,6 +925,7 @@ constexpr int QS2_T = PB * PB <= 1024 ? PB * PB : 1024;
 template <int NL, bool TRANS>
 __global__ void __launch_bounds__(QS2_T) k_qsolve_panel2(Batch Q, Batch Linv, mw::Ptr rhs, mw::Ptr out, int k0)
 {
+  raise_chain_priority();
   static_assert(PB * PB <= 1024, "one lane per (row, column) of a panel");
   const MatDesc dq = Q.d[0], di = Linv.d[0];
   const int N = dq.rows, nb = di.rows, t = threadIdx.x;

@@ -1981,6 +1981,30 @@ public:
   // sdpb_hip_bench_op: average HIP-event time of one kernel on synthetic operands (ms)
   double bench_op(const std::string &op, int a, int b, int reps) override
   {
+    if(op == "trsm")
+      {
+        // P = L^{-1} B with the solver's own blocks and the factors of the last iteration (a = b = 0)
+        if(iteration_ == 0)
+          throw SolverError(4, "bench_op trsm: run an iteration first");
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        float total = 0;
+        for(int r = 0; r < std::max(reps, 1); ++r)
+          {
+            copy(BT_, PT_);
+            HIP_CHECK(hipEventRecord(e0, stream_));
+            trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_);
+            HIP_CHECK(hipEventRecord(e1, stream_));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms;
+          }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return total / std::max(reps, 1);
+      }
     if(op != "syrk" || a <= 0 || b <= 0)
       throw SolverError(4, "bench_op: unknown op " + op);
     const int rows = a, cols = b;
