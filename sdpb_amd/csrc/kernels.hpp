@@ -917,65 +917,100 @@ __global__ void __launch_bounds__(WG) k_qsolve_panel(Batch Q, Batch Linv, mw::Pt
     }
 }
 
-// The same panel step with the dependent chain cut to 2 x (one product + a log2(PB)-level tree):
-// 1024-lane workgroups, lane (i, k) forms ONE product of row i's dot product and the PB partial
-// products of a row meet in an LDS tree.  The substitution is a chain of 2 N/PB such launches per
-// right-hand side, replicated on every GPU, so its length is what matters (49 -> ~20 us per launch).
+// The same panel step with the dependent chain cut to 2 x (one product + a two-level sum):
+// 1024-lane workgroups, lane (i, k) forms ONE product of row i's dot product; the PB products of a
+// row meet in a limb-major (conflict-free) LDS image and are summed exactly, eight at a time by four
+// lanes and then by one (mw::Acc: an aligned add per term, one rounding per level), instead of a
+// five-level tree of rounded adds over an array of 80-byte structures.  Every operand that does not
+// depend on the first sum is loaded before it (the rows of L outside the panel, the old right-hand
+// side).  In the transposed (backward) sweep the column index is the fast lane index (L(k0+k, r) is
+// contiguous in k): with the row index fast every lane read a cache line of its own, 14 instead of 3 us
+// before the first product.  Measured per launch on C4 with the in-kernel clock (forward / backward):
+//   five-level tree, row index fast in both sweeps                43 / 47 us
+//   this kernel                                                   38 / 35 us
+//   256 lanes x 4 products in one accumulator, sum of 8           39 / 39 us
+//   512 lanes x 2 products, sums 4 + 4                            38 / 40 us
+// (a lone wavefront issues a multiply-add pair every 18 cycles, half of what its SIMD can take, and an
+// aligned add costs it ~1 us: fewer, fatter lanes do not pay).  The substitution is a chain of 2 N/PB
+// such launches per right-hand side, replicated on every GPU, so its length is what matters.
 constexpr int QS2_T = PB * PB <= 1024 ? PB * PB : 1024;
+constexpr int QS2_G = PB < 4 ? PB : 4; // lanes per row in the first level of the sum
+#ifdef SDPB_QS_TRACE
+__device__ long long qs_trace[2][64][8];
+#define QS_MARK(n)                                                                                                                         \
+  if(blockIdx.x == 0 && threadIdx.x == 0)                                                                                                    \
+  qs_trace[TRANS ? 1 : 0][(k0 / PB) & 63][n] = wall_clock64()
+#else
+#define QS_MARK(n)
+#endif
 template <int NL, bool TRANS>
 __global__ void __launch_bounds__(QS2_T) k_qsolve_panel2(Batch Q, Batch Linv, mw::Ptr rhs, mw::Ptr out, int k0)
 {
   raise_chain_priority();
-  static_assert(PB * PB <= 1024, "one lane per (row, column) of a panel");
+  QS_MARK(0);
+  static_assert(PB * PB <= 1024 && PB % QS2_G == 0, "one lane per (row, column) of a panel");
   const MatDesc dq = Q.d[0], di = Linv.d[0];
   const int N = dq.rows, nb = di.rows, t = threadIdx.x;
-  const int i = t % PB, k = t / PB;
-  __shared__ Mw<NL> sx[PB], part[QS2_T];
-  if(t < nb)
-    sx[t] = mw::load<NL>(rhs, (size_t)k0 + t);
+  // product lanes (ip, kp): the fast lane index runs along memory.  Row i's products sit at slots
+  // i (PB+1) + k in the transposed sweep (odd stride: the writes along k and the reads along i are
+  // both conflict-free), at k PB + i in the forward sweep.
+  const int ip = TRANS ? t / PB : t % PB, kp = TRANS ? t % PB : t / PB;
+  // summing lanes: row i1, group g1
+  const int i1 = t % PB, g1 = t / PB;
+  constexpr int STR = PB * (PB + 1);
+  auto slot = [](int i, int k) { return TRANS ? i * (PB + 1) + k : k * PB + i; };
+  __shared__ uint32_t part[(NL + 2) * STR], sx[(NL + 2) * PB];
+  const int first = TRANS ? 0 : k0 + nb, count = TRANS ? k0 : N - k0 - nb;
+  const int rp = blockIdx.x * PB + ip, r1 = blockIdx.x * PB + i1;
+  const bool tri = ip < nb && kp < nb && (TRANS ? kp >= ip : kp <= ip), upd = rp < count && kp < nb;
+  const Mw<NL> li = tri ? (TRANS ? mat_ld<NL>(Linv, di, kp, ip) : mat_ld<NL>(Linv, di, ip, kp)) : mw::zero<NL>();
+  const Mw<NL> lq = upd ? (TRANS ? mat_ld<NL>(Q, dq, k0 + kp, first + rp) : mat_ld<NL>(Q, dq, first + rp, k0 + kp)) : mw::zero<NL>();
+  const bool last = g1 == 0 && r1 < count;
+  const Mw<NL> old = last ? mw::load<NL>(rhs, (size_t)first + r1) : mw::zero<NL>(); // not touched by this launch before its own store
+  if(t < PB)
+    smem_st<NL, PB>(sx, t, t < nb ? mw::load<NL>(rhs, (size_t)k0 + t) : mw::zero<NL>());
   __syncthreads();
-  auto tree = [&]() __attribute__((always_inline)) {
-    for(int s = PB / 2; s > 0; s >>= 1)
+  QS_MARK(1);
+  // level 1 of the sum over k: lanes g1 < QS2_G take every QS2_G-th product of their row
+  auto level1 = [&](const Mw<NL> &p) __attribute__((always_inline)) {
+    smem_st<NL, STR>(part, slot(ip, kp), p);
+    __syncthreads();
+    if(g1 < QS2_G)
       {
-        __syncthreads();
-        if(k < s && k + s < PB)
-          part[t] = mw::add(part[t], part[t + s * PB]);
+        Acc<NL> a = mw::acc_zero<NL>();
+        for(int kk = g1; kk < nb; kk += QS2_G)
+          mw::acc_add(a, smem_ld<NL, STR>(part, slot(i1, kk)));
+        smem_st<NL, STR>(part, slot(i1, g1), mw::acc_result(a)); // in place: this slot is read by this lane only
       }
     __syncthreads();
   };
   // xp = Linv_pp rhs_p (lower triangular; TRANS: its transpose)
-  {
-    Mw<NL> p = mw::zero<NL>();
-    if(i < nb && k < nb && (TRANS ? k >= i : k <= i))
-      p = mw::mul(TRANS ? mat_ld<NL>(Linv, di, k, i) : mat_ld<NL>(Linv, di, i, k), sx[k]);
-    part[t] = p;
-  }
-  tree();
-  if(t < nb)
+  level1(mw::mul(li, smem_ld<NL, PB>(sx, kp)));
+  QS_MARK(2);
+  if(g1 == 0)
     {
-      sx[t] = part[t]; // every partial of column block 0 is read before this write (barrier in tree)
-      if(blockIdx.x == 0)
-        mw::store<NL>(out, (size_t)k0 + t, part[t]);
+      Acc<NL> a = mw::acc_zero<NL>();
+      for(int g = 0; g < QS2_G; ++g)
+        mw::acc_add(a, smem_ld<NL, STR>(part, slot(i1, g)));
+      const Mw<NL> xp = mw::acc_result(a);
+      smem_st<NL, PB>(sx, i1, xp); // every lane read its sx[kp] before the barriers of level1
+      if(blockIdx.x == 0 && i1 < nb)
+        mw::store<NL>(out, (size_t)k0 + i1, xp);
     }
   __syncthreads();
+  QS_MARK(3);
   // rows outside the panel: rhs[r] -= sum_k L(r, k0 + k) xp[k]
-  const int first = TRANS ? 0 : k0 + nb, count = TRANS ? k0 : N - k0 - nb;
-  const int ri = blockIdx.x * PB + i;
-  {
-    Mw<NL> p = mw::zero<NL>();
-    if(ri < count && k < nb)
-      {
-        const int r = first + ri;
-        p = mw::mul(TRANS ? mat_ld<NL>(Q, dq, k0 + k, r) : mat_ld<NL>(Q, dq, r, k0 + k), sx[k]);
-      }
-    part[t] = p;
-  }
-  tree();
-  if(k == 0 && ri < count)
+  level1(mw::mul(lq, smem_ld<NL, PB>(sx, kp)));
+  QS_MARK(4);
+  if(last)
     {
-      const size_t r = (size_t)first + ri;
-      mw::store<NL>(rhs, r, mw::sub(mw::load<NL>(rhs, r), part[t]));
+      Acc<NL> a = mw::acc_zero<NL>();
+      mw::acc_add(a, old);
+      for(int g = 0; g < QS2_G; ++g)
+        mw::acc_add(a, smem_ld<NL, STR>(part, slot(i1, g)), 1u);
+      mw::store<NL>(rhs, (size_t)first + r1, mw::acc_result(a));
     }
+  QS_MARK(5);
 }
 
 // ---------------------------------------------------------------------------
@@ -1348,7 +1383,9 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
   const BlockDesc bl = blk[j];
   const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
   const int p = blockIdx.x * 4 + sub;
-  __shared__ Mw<NL> sm[WG];
+  // the 64 partial sums of a row meet in a limb-major LDS image and are added exactly, eight at a time
+  // by eight lanes and then by one (two barriers instead of a six-level tree of rounded adds)
+  __shared__ uint32_t sm[(NL + 2) * WG];
   Acc<NL> sum = mw::acc_zero<NL>();
   if(p < bl.P)
     {
@@ -1356,20 +1393,23 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
       for(int n = lane; n < N; n += 64)
         mw::acc_fma(sum, mat_ld<NL>(MT, dm, n, p), mw::load<NL>(v, n));
     }
-  sm[threadIdx.x] = mw::acc_result(sum);
+  smem_st<NL, WG>(sm, threadIdx.x, mw::acc_result(sum));
   __syncthreads();
-  for(int s = 32; s > 0; s >>= 1)
+  if(lane < 8)
     {
-      if(lane < s)
-        sm[threadIdx.x] = mw::add(sm[threadIdx.x], sm[threadIdx.x + s]);
-      __syncthreads();
+      Acc<NL> a = mw::acc_zero<NL>();
+      for(int g = 0; g < 8; ++g)
+        mw::acc_add(a, smem_ld<NL, WG>(sm, sub * 64 + g * 8 + lane));
+      smem_st<NL, WG>(sm, threadIdx.x, mw::acc_result(a)); // slot sub*64 + lane: read by this lane only (g = 0)
     }
+  __syncthreads();
   if(lane == 0 && p < bl.P)
     {
-      Mw<NL> r = sm[threadIdx.x];
-      if(sign < 0)
-        r = mw::neg(r);
-      mw::store<NL>(out, (size_t)bl.voff + p, mw::add(mw::load<NL>(out, (size_t)bl.voff + p), r));
+      Acc<NL> a = mw::acc_zero<NL>();
+      mw::acc_add(a, mw::load<NL>(out, (size_t)bl.voff + p));
+      for(int g = 0; g < 8; ++g)
+        mw::acc_add(a, smem_ld<NL, WG>(sm, sub * 64 + g), sign < 0 ? 1u : 0u);
+      mw::store<NL>(out, (size_t)bl.voff + p, mw::acc_result(a));
     }
 }
 
@@ -2573,6 +2613,12 @@ __device__ inline int sturm_count_f64(const double *a, const double *b2, int n, 
 #define SDPB_TRI_T 128
 #endif
 constexpr int TRI_T = SDPB_TRI_T;
+#ifndef SDPB_TRI_WAVES
+#define SDPB_TRI_WAVES 2
+#endif
+// (A two-level exact sum through a limb-major image, as in k_gemv_n, was measured here and is slower:
+// 4.74 instead of 4.61 ms per launch; every lane needs the result, and the kernel is bound by the
+// wavefront-instructions it issues, not by the depth of this tree.)
 template <int NL> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
 {
   const int t = threadIdx.x;
@@ -2588,7 +2634,7 @@ template <int NL> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
   __syncthreads();
   return r;
 }
-template <int NL> __global__ void __launch_bounds__(TRI_T) k_tridiag(Batch A, Batch D, Batch E)
+template <int NL> __global__ void __launch_bounds__(TRI_T, SDPB_TRI_WAVES) k_tridiag(Batch A, Batch D, Batch E)
 {
   const int q = blockIdx.x;
   const MatDesc d = A.d[q];

@@ -1981,6 +1981,25 @@ public:
   // sdpb_hip_bench_op: average HIP-event time of one kernel on synthetic operands (ms)
   double bench_op(const std::string &op, int a, int b, int reps) override
   {
+#ifdef SDPB_QS_TRACE
+    if(op == "qstrace")
+      {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        static long long h[2][64][8];
+        HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(qs_trace), sizeof(h)));
+        for(int d = 0; d < 2; ++d)
+          for(int p = 0; p < 32; p += 5)
+            {
+              fprintf(stderr, "qstrace dir %d panel %2d:", d, p);
+              for(int m = 1; m < 6; ++m)
+                fprintf(stderr, " %6.2f", (double)(h[d][p][m] - h[d][p][m - 1]) * 0.01);
+              if(p + 1 < 32)
+                fprintf(stderr, "   next start - this end %6.2f us", (double)(h[d][d ? (p ? p - 1 : 0) : p + 1][0] - h[d][p][5]) * 0.01);
+              fprintf(stderr, "\n");
+            }
+        return 0;
+      }
+#endif
     if(op == "trsm")
       {
         // P = L^{-1} B with the solver's own blocks and the factors of the last iteration (a = b = 0)
