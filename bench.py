@@ -292,6 +292,10 @@ def main():
         k_bytes = timers1["kernel.k_syrk_fx.algorithmic_bytes"]
         k_macs = timers1["kernel.k_syrk_fx.limb_macs"]
         achieved = k_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        # which instantiation that is: two Karatsuba levels keep 7 spare bits in the image, one level 3
+        fb = solver.fx_frac_bits()
+        fx = (fb + 7) // 32
+        k_name = (f"k_syrk_fx2<{fx},32>" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}>") + " (+k_syrk_reduce)"
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_k_syrk_fx.json")
         if os.path.exists(pmc) and args.workload == "C4" and args.scale == 1.0 and world == 1:
@@ -316,7 +320,7 @@ def main():
                        "parallelism": f"blocks sharded over {world} GPU(s); Q' summed by integer all-reduce",
                        "exchange": solver.comm_name},
             "host_syncs_per_step": (syncs1 - syncs0) / args.steps,
-            "roofline": {"bound": "hbm", "kernel": "k_syrk_fx", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": k_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r02_pmc_k_syrk_fx.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                            "command, FETCH_SIZE x2 per MI355X_MICROARCH.md)" if traffic else None,

@@ -146,7 +146,9 @@ int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx);
 /* Measurement aid (bench/profiling only, never on the solve path): average HIP-event time in
  * ms of `reps` launches of one kernel of the iteration on synthetic device-resident operands.
  * op = "syrk": the exact integer Q' = P'^T P' (k_syrk_fx / k_syrk_fx2 + k_syrk_reduce) for a
- * `a` x `b` fixed-point image of pseudo-random pieces. */
+ * `a` x `b` fixed-point image of pseudo-random pieces.
+ * op = "trsm" (a = b = 0): P = L^{-1} B (k_trsm_rlt_panel over all panels) with the solver's own
+ * blocks and the Schur-complement factors of its last iteration; needs one iteration first. */
 int sdpb_hip_bench_op(sdpb_hip_ctx *ctx, const char *op, int a, int b, int reps, double *ms);
 
 /* Cross-GPU exchange (world_size > 1), replacing the El::mpi collectives listed in
