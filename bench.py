@@ -293,7 +293,7 @@ def main():
         k_macs = timers1["kernel.k_syrk_fx.limb_macs"]
         achieved = k_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         # which instantiation that is: two Karatsuba levels keep 7 spare bits in the image, one level 3
-        fb = solver.fx_frac_bits()
+        fb = solver.fx_frac_bits
         fx = (fb + 7) // 32
         k_name = (f"k_syrk_fx2<{fx},32>" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}>") + " (+k_syrk_reduce)"
         traffic = None
