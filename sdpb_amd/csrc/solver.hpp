@@ -322,6 +322,17 @@ template <int NL> class Solver : public SolverBase
   hipStream_t stream_q_ = nullptr; // Cholesky(Q) runs here, concurrently with stream_
   hipEvent_t ev_q_ready_ = nullptr, ev_q_done_ = nullptr, ev_la_strip_ = nullptr, ev_la_bulk_ = nullptr;
   hipStream_t stream_q2_ = nullptr; // bulk updates of the look-ahead Cholesky(Q)
+  // While the factorisation of Q is pending, the main stream's work (residues, the predictor's Q-independent
+  // part) is throughput work that fills every CU, and the chain's single workgroups then wait for wavefront
+  // slots and LDS (0.75 instead of 0.41 ms per panel).  That stretch of the main stream therefore runs on a
+  // stream whose CU mask leaves R compute units free (hipExtStreamCreateWithCUMask); the syrk and everything
+  // after the join stay on the unmasked stream.  Measured on C4 (profiles/r02l_beside_cus.txt), R = 0 / 16 /
+  // 32 / 64 / 128: wait at the join 5.5 / 3.1 / 2.0 / 0.55 / 0.02 ms, iteration 281.5 / 280.4 / 280.4 / 279.5 /
+  // 281.1 ms.  Default R = a quarter of the CUs with one rank; with several ranks (collectives inside the
+  // stretch, less work to hide) only on request: SDPB_HIP_BESIDE_CUS=R, 0 switches it off.
+  hipStream_t stream_beside_ = nullptr;
+  hipEvent_t ev_beside_ = nullptr;
+  bool beside_active_ = false;
   bool q_pending_ = false;
   bool single_stream_ = false;
   hipEvent_t ev_syrk0_ = nullptr, ev_syrk1_ = nullptr;
@@ -377,6 +388,26 @@ public:
           HIP_CHECK(hipStreamCreateWithPriority(&stream_q2_, hipStreamNonBlocking, prio));
         }
     }
+    {
+      int reserve = world_ == 1 ? num_cus_ / 4 : 0;
+      if(const char *e = std::getenv("SDPB_HIP_BESIDE_CUS"))
+        reserve = std::atoi(e);
+      if(reserve > 0 && reserve < num_cus_ && !single_stream_)
+        {
+          std::vector<uint32_t> mask((num_cus_ + 31) / 32, 0u);
+          for(int cu = 0; cu < num_cus_; ++cu)
+            if((cu * 37) % num_cus_ >= reserve) // the reserved ones are spread over the XCDs
+              mask[cu / 32] |= 1u << (cu % 32);
+          // an optimisation only: a runtime that refuses the mask leaves the schedule as it was
+          if(hipExtStreamCreateWithCUMask(&stream_beside_, (uint32_t)mask.size(), mask.data()) != hipSuccess)
+            {
+              (void)hipGetLastError();
+              stream_beside_ = nullptr;
+            }
+          else
+            HIP_CHECK(hipEventCreateWithFlags(&ev_beside_, hipEventDisableTiming));
+        }
+    }
     HIP_CHECK(hipEventCreateWithFlags(&ev_la_strip_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_la_bulk_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&ev_q_ready_));
@@ -396,6 +427,11 @@ public:
       (void)hipEventDestroy(ev_la_strip_);
     if(ev_la_bulk_)
       (void)hipEventDestroy(ev_la_bulk_);
+    leave_beside_stream();
+    if(ev_beside_)
+      (void)hipEventDestroy(ev_beside_);
+    if(stream_beside_)
+      (void)hipStreamDestroy(stream_beside_);
     if(stream_q2_ && !single_stream_)
       (void)hipStreamDestroy(stream_q2_);
     if(stream_q_ && !single_stream_)
@@ -1402,10 +1438,29 @@ private:
     blocked_cholesky_lookahead(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags, stream_q_, stream_q2_);
     HIP_CHECK(hipEventRecord(ev_q_done_, stream_q_));
     q_pending_ = true;
+    if(stream_beside_ && !beside_active_)
+      {
+        HIP_CHECK(hipEventRecord(ev_beside_, stream_));
+        HIP_CHECK(hipStreamWaitEvent(stream_beside_, ev_beside_, 0));
+        std::swap(stream_, stream_beside_);
+        beside_active_ = true;
+      }
+  }
+  // back to the unmasked main stream, ordered after what the masked one was given (no-throw: also
+  // called from the destructor and at the start of an iteration that follows an exception)
+  void leave_beside_stream() noexcept
+  {
+    if(!beside_active_)
+      return;
+    (void)hipEventRecord(ev_beside_, stream_);
+    std::swap(stream_, stream_beside_);
+    (void)hipStreamWaitEvent(stream_, ev_beside_, 0);
+    beside_active_ = false;
   }
   // the main stream waits for the factor of Q (device-side); failures become tags
   void join_cholesky_Q()
   {
+    leave_beside_stream();
     if(!q_pending_)
       return;
     q_pending_ = false;
@@ -1705,6 +1760,7 @@ public:
         start_time_ = std::chrono::steady_clock::now();
       }
     iteration_ += 1;
+    leave_beside_stream();
     Timer whole(this, "iteration");
     if(profile_)
       profiled_iterations_ += 1;

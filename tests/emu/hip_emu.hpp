@@ -151,6 +151,11 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
   *s = nullptr;
   return hipSuccess;
 }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *)
+{
+  *s = nullptr;
+  return hipSuccess;
+}
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int)
 {
   *s = nullptr;
