@@ -233,6 +233,13 @@ int sdpb_hip_op_scalar(sdpb_hip_ctx *ctx, const char *op, const char *a, const c
  * cols x cols product, column-major, one integer per line. */
 int sdpb_hip_op_int_syrk(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, char *buf, size_t buflen,
                          size_t *needed);
+/* syrk_Q as an operator (compute_Q.cxx:94-132: Matrix_Normalizer column norms,
+ * normalize_and_shift, the exact integer syrk, check_normalized_Q_diagonal, restore_Q) — the
+ * stage the reference unit-tests in test/src/unit_tests/cases/calculate_matrix_square.test.cxx.
+ * P: rows x cols decimals, column-major; result: lower triangle of Q = P^T P, cols x cols
+ * column-major (upper part zero), one decimal per line.  Returns 1 with the reference's
+ * "Normalized Q should have ones on diagonal" text if the check fails. */
+int sdpb_hip_op_syrk_Q(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, char *buf, size_t buflen, size_t *needed);
 /* Host-side fixed-point exchange image helpers (used by the world_size-2 gloo tests to
  * check the u64-lane reduction without a GPU): encode a two's-complement integer given
  * in decimal into `planes` 32-bit limbs widened to uint64 lanes; decode after a lane-wise

@@ -411,6 +411,16 @@ int sdpb_hip_op_int_syrk(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, c
   return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
 }
 
+int sdpb_hip_op_syrk_Q(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] {
+    if(!P)
+      throw sdpb::SolverError(4, "sdpb_hip_op_syrk_Q: null argument");
+    ctx->strbuf = ctx->solver->op_syrk_Q(rows, cols, P);
+  });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
+}
+
 int sdpb_hip_host_encode_u64(const char *s, int planes, unsigned long long *lanes)
 {
   if(!s || !lanes || planes <= 0)

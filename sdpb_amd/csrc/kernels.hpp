@@ -1636,7 +1636,7 @@ __global__ void __launch_bounds__(WG) k_normalize_fx(mw::CPtr PT, size_t count, 
       uint32_t v[FX];
 #pragma unroll
       for(int i = 0; i < FX; ++i)
-        v[i] = sat ? ((i == FX - 1) ? 0x1fffffffu : 0xffffffffu) : w[i];
+        v[i] = sat ? ((i == FX - 1) ? ((1u << (FB % 32)) - 1u) : 0xffffffffu) : w[i]; // 2^FB - 1 for either image (FB = 32FX-3 or 32FX-7)
       fx_store<FX>(v, t.neg != 0, fx, fx_stride, idx);
     }
 }

@@ -47,6 +47,11 @@ struct RcclComm : Comm
     check(ncclAllReduce(buf, buf, count, ncclUint64, ncclSum, comm, st), "ncclAllReduce");
   }
   const char *name() const override { return "rccl"; }
+  int ranks() const override
+  {
+    int n = 0;
+    return ncclCommCount(comm, &n) == ncclSuccess ? n : 0;
+  }
 };
 inline Comm *make_rccl_comm(const void *id, size_t id_bytes, int rank, int world) { return new RcclComm(id, id_bytes, rank, world); }
 inline size_t rccl_unique_id(void *out, size_t capacity)

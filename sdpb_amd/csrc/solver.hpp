@@ -52,6 +52,7 @@ struct Comm
   virtual void allgather(const void *dev_send, void *dev_recv, size_t bytes, hipStream_t st) = 0;
   virtual void allreduce_sum_u64(void *dev_buf, size_t count, hipStream_t st) = 0;
   virtual const char *name() const = 0;
+  virtual int ranks() const { return -1; } // size of the communicator as the transport reports it (-1: opaque callbacks)
 };
 struct CallbackComm : Comm
 {
@@ -187,6 +188,7 @@ public:
   // operator-level entry points for parity tests
   virtual std::string op_scalar(const std::string &op, const char *a, const char *b) = 0;
   virtual std::string op_int_syrk(int rows, int cols, const char *ints_colmajor) = 0;
+  virtual std::string op_syrk_Q(int rows, int cols, const char *P_colmajor) = 0;
 };
 
 template <class... KArgs, class... Args>
@@ -292,6 +294,9 @@ template <int NL> class Solver : public SolverBase
   std::vector<M> res_host_ = std::vector<M>(R_COUNT);
   uint32_t xw_host_[X_EXTRA] = {0xffffffffu, 0, 0, 0};
   std::unique_ptr<Comm> comm_;
+  // what this rank handed to the exchange (bench.py: proof that N ranks exchanged, and how much)
+  long xc_allgather_calls_ = 0, xc_allreduce_calls_ = 0;
+  double xc_allgather_bytes_ = 0, xc_allreduce_bytes_ = 0;
   long host_syncs_ = 0;
   bool profile_ = false;
   // SDPB_HIP_OVERLAP_SYRK=1 moves the Q chain to the side stream (experiment, measured on C4: the VALU-bound
@@ -701,7 +706,10 @@ public:
        << ", \"kernel.k_syrk_fx.limb_macs\": "
        << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 9 (FX/4)^2 or 3 (FX/2)^2 per product
        << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TWO_LEVEL ? 2 : 1) << ", \"host_syncs\": " << host_syncs_
-       << ", \"iterations\": " << iteration_;
+       << ", \"iterations\": " << iteration_ << ", \"comm.world\": " << world_ << ", \"comm.ranks\": " << (comm_ ? comm_->ranks() : (world_ == 1 ? 1 : 0))
+       << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
+       << ", \"comm.allgather_bytes\": " << xc_allgather_bytes_ << ", \"comm.allreduce_calls\": " << xc_allreduce_calls_
+       << ", \"comm.allreduce_bytes\": " << xc_allreduce_bytes_;
     ss << "}";
     return ss.str();
   }
@@ -925,6 +933,8 @@ private:
       o = X_KEEP;
     for(auto &so : slot_ops)
       ops.op[so.first] = so.second;
+    xc_allgather_calls_ += 1;
+    xc_allgather_bytes_ += (double)(RES_WORDS * sizeof(uint32_t));
     comm().allgather(resbuf_.p, xgather_.p, RES_WORDS * sizeof(uint32_t), stream_);
     launch(k_combine_slots<NL>, dim3(1), dim3(64), stream_, (const uint32_t *)xgather_.p, world_, (int)R_COUNT, ops, resbuf_.p);
   }
@@ -991,6 +1001,8 @@ private:
         HIP_CHECK(hipDeviceSynchronize());
         xgather_.alloc(words * world_);
       }
+    xc_allgather_calls_ += 1;
+    xc_allgather_bytes_ += (double)(words * sizeof(uint32_t));
     comm().allgather(a.base, xgather_.p, words * sizeof(uint32_t), stream_);
     launch(k_combine_vec<NL>, dim3(cdiv(count, WG)), dim3(WG), stream_, (const uint32_t *)xgather_.p, world_, (int)count, a.ptr());
   }
@@ -1322,22 +1334,7 @@ private:
       // syrk_Q, compute_Q.cxx:94-132
       Timer t(this, "initializeSchurComplementSolver.Q.syrk");
       gemv_t_all<true>(PT_, x_, nullptr, 1, norms_, side ? part2_ : part_); // norms_ = column norms^2 (Matrix_Normalizer.cxx:75-137)
-      {
-        mw::Ptr nr = norms_.ptr(), inv = invnorms_.ptr();
-        foreach((size_t)N_, [=] __device__(size_t i) {
-          const M n2 = mw::load<NL>(nr, i);
-          if(mw::is_zero(n2))
-            {
-              mw::store<NL>(inv, i, n2);
-              return;
-            }
-          const M r = mw::rsqrt(n2);
-          M s = mw::mul(n2, r);
-          s = mw::add(s, mw::mul_2exp(mw::mul(r, mw::sub(n2, mw::mul(s, s))), -1));
-          mw::store<NL>(nr, i, s);
-          mw::store<NL>(inv, i, mw::mul(r, mw::sub(mw::from_u32<NL>(2), mw::mul(s, r))));
-        });
-      }
+      norms_to_inverse(norms_.ptr(), invnorms_.ptr(), (size_t)N_);
       const size_t cnt = Ptot_ * (size_t)N_;
       if(cnt)
         launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT_.cptr(), cnt, N_, // one element per lane: streams at HBM rate
@@ -1373,6 +1370,23 @@ private:
     }
     if(!side)
       cholesky_Q_async();
+  }
+  // norms^2 -> norms (in place) and 1/norm (Matrix_Normalizer.cxx:133-136); a zero column keeps 0
+  void norms_to_inverse(mw::Ptr nr, mw::Ptr inv, size_t n)
+  {
+    foreach(n, [=] __device__(size_t i) {
+      const M n2 = mw::load<NL>(nr, i);
+      if(mw::is_zero(n2))
+        {
+          mw::store<NL>(inv, i, n2);
+          return;
+        }
+      const M r = mw::rsqrt(n2);
+      M s = mw::mul(n2, r);
+      s = mw::add(s, mw::mul_2exp(mw::mul(r, mw::sub(n2, mw::mul(s, s))), -1));
+      mw::store<NL>(nr, i, s);
+      mw::store<NL>(inv, i, mw::mul(r, mw::sub(mw::from_u32<NL>(2), mw::mul(s, r))));
+    });
   }
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
   // that fills the last round of resident workgroups better; `part` grows on demand
@@ -1421,6 +1435,8 @@ private:
     const size_t T = (size_t)N_ * (N_ + 1) / 2 + N_;
     const dim3 grid(cdiv(N_, WG), N_ + 1);
     launch(k_widen_tri_u64<0>, grid, dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_, (int)ACCW, acc64_.p);
+    xc_allreduce_calls_ += 1;
+    xc_allreduce_bytes_ += (double)(T * ACCW * 8);
     comm().allreduce_sum_u64(acc64_.p, T * ACCW, stream_);
     launch(k_narrow_tri_carry<0>, grid, dim3(WG), stream_, (const unsigned long long *)acc64_.p, N_, (int)ACCW, acc_.p, acc_stride_);
   }
@@ -2113,6 +2129,69 @@ public:
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return ms / std::max(reps, 1);
+  }
+
+  // syrk_Q as an operator (compute_Q.cxx:94-132): column norms, normalise-and-shift, the exact
+  // integer syrk, the diagonal check and the restore, on a rows x cols matrix P given column-major as
+  // decimals — the reference's own unit test of this stage is calculate_matrix_square.test.cxx
+  // (random P, compare with plain P^T P to p/2 bits).  Returns the lower triangle of Q = P^T P
+  // (cols x cols column-major, upper part zero).  Same kernels, same order as the iteration.
+  std::string op_syrk_Q(int rows, int cols, const char *txt) override
+  {
+    if(rows <= 0 || cols <= 0)
+      throw SolverError(4, "op_syrk_Q: rows and cols must be positive");
+    const size_t cnt = (size_t)rows * cols;
+    const std::vector<M> in = parse_list(txt, cnt, "P");
+    // P^T (cols x rows column-major): element (r, n) at r*cols + n, the layout of PT_
+    std::vector<M> pt(cnt);
+    for(int c = 0; c < cols; ++c)
+      for(int r = 0; r < rows; ++r)
+        pt[(size_t)r * cols + c] = in[(size_t)c * rows + r];
+    DevArray PT, part, nrm, inv, Q;
+    PT.alloc(cnt, NL);
+    part.alloc(cols, NL);
+    nrm.alloc(cols, NL);
+    inv.alloc(cols, NL);
+    Q.alloc((size_t)cols * cols, NL);
+    upload<NL>(PT, 0, pt);
+    BlockDesc bd{};
+    bd.P = rows;
+    bd.voff = 0;
+    DevBuf<BlockDesc> dbd;
+    dbd.upload(std::vector<BlockDesc>{bd});
+    DevBuf<MatDesc> dmd;
+    dmd.upload(std::vector<MatDesc>{MatDesc{0, cols, rows, cols, 0}});
+    launch(k_gemv_t_partial<NL, true>, dim3(cdiv(cols, WG), 1), dim3(WG), stream_, Batch{PT.ptr(), dmd.p, 1}, PT.cptr(), part.ptr(),
+           (const BlockDesc *)dbd.p, cols);
+    launch(k_sum_partials<NL>, dim3(cdiv(cols, SP_ROWS)), dim3(WG), stream_, part.cptr(), 1, cols, nrm.cptr(), 0, 1, nrm.ptr());
+    norms_to_inverse(nrm.ptr(), inv.ptr(), (size_t)cols);
+    DevBuf<uint32_t> fx, acc, partial, tl, spart;
+    DevBuf<int> qf;
+    fx.alloc(cnt * fx_planes<FX>());
+    launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT.cptr(), cnt, cols, inv.cptr(), fx.p, cnt);
+    const size_t as = (size_t)cols * cols + cols;
+    acc.alloc(as * ACCW);
+    const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
+    partial.alloc((size_t)slices * (FX + 8) * cols);
+    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices);
+    tl.upload(syrk_tile_order(cols));
+    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, spart);
+    qf.alloc(4);
+    HIP_CHECK(hipMemsetAsync(qf.p, 0, 4 * sizeof(int), stream_));
+    launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows);
+    launch(k_restore_Q<NL, FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, (const uint32_t *)acc.p, as, cols, nrm.cptr(),
+           Q.ptr(), qf.p + 1);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const std::vector<int> flags = qf.download();
+    if(flags[1]) // compute_Q.cxx:65-91
+      throw SolverError(1, "Normalized Q should have ones on diagonal. For i = " + std::to_string(flags[1] - 1));
+    std::string out;
+    for(const M &e : download<NL>(Q, 0, (size_t)cols * cols))
+      {
+        out += mw::to_decimal<NL>(e);
+        out += "\n";
+      }
+    return out;
   }
 
   // Exact integer syrk of a rows x cols integer matrix (column-major decimal

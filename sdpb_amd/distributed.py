@@ -28,12 +28,23 @@ def tensor_from_pointer(ptr: int, nbytes: int, device: torch.device) -> torch.Te
 
 
 def make_collectives(device: torch.device, group=None):
-    """Returns (allreduce_sum_u64, allgather_bytes) for SDPSolver.set_collectives."""
+    """Returns (allreduce_sum_u64, allgather_bytes) for SDPSolver.set_collectives.
+
+    With device memory and a host-only backend (`gloo`: several ranks sharing ONE GPU, which
+    RCCL refuses — the multi-rank device tests on a 1-GPU box) the buffers are staged through
+    host memory around each collective."""
     world = dist.get_world_size(group)
+    staged = device.type == "cuda" and dist.get_backend(group) == "gloo"
 
     def allreduce_sum_u64(ptr, count):
         try:
             t = tensor_from_pointer(ptr, count * 8, device).view(torch.int64)
+            if staged:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+                torch.cuda.current_stream(device).synchronize()
+                return 0
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # wrapping int64 sum == uint64 sum
             if device.type == "cuda":
                 # only the stream the collective was ordered on: the library keeps an independent
@@ -48,6 +59,13 @@ def make_collectives(device: torch.device, group=None):
         try:
             s = tensor_from_pointer(send, nbytes, device)
             r = tensor_from_pointer(recv, nbytes * world, device)
+            if staged:
+                hs = s.cpu()
+                hr = torch.empty(world, nbytes, dtype=torch.uint8)
+                dist.all_gather(list(hr.unbind(0)), hs, group=group)
+                r.copy_(hr.view(-1))
+                torch.cuda.current_stream(device).synchronize()
+                return 0
             dist.all_gather_into_tensor(r, s, group=group) if device.type == "cuda" else \
                 dist.all_gather(list(r.view(world, nbytes).unbind(0)), s, group=group)
             if device.type == "cuda":

@@ -126,6 +126,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_op_scalar.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 4 + [ctypes.c_size_t, size_p]
     L.sdpb_hip_op_int_syrk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                        ctypes.c_char_p, ctypes.c_size_t, size_p]
+    L.sdpb_hip_op_syrk_Q.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                     ctypes.c_char_p, ctypes.c_size_t, size_p]
     ull_p = ctypes.POINTER(ctypes.c_ulonglong)
     L.sdpb_hip_host_encode_u64.argtypes = [ctypes.c_char_p, ctypes.c_int, ull_p]
     L.sdpb_hip_host_decode_u64.argtypes = [ull_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, size_p]
@@ -379,6 +381,12 @@ class SDPSolver:
     def op_int_syrk(self, rows: int, cols: int, ints_colmajor) -> List[int]:
         txt = " ".join(str(v) for v in ints_colmajor).encode()
         return [int(s) for s in self._string(self.L.sdpb_hip_op_int_syrk, rows, cols, txt).split()]
+
+    def op_syrk_Q(self, rows: int, cols: int, P_colmajor) -> List[str]:
+        """Q = P^T P through the whole syrk_Q stage (norms, fixed-point image, exact integer syrk,
+        diagonal check, restore): lower triangle, column-major decimals."""
+        txt = " ".join(str(v) for v in P_colmajor).encode()
+        return self._string(self.L.sdpb_hip_op_syrk_Q, rows, cols, txt).split()
 
     def block_timings(self) -> List[int]:
         """Microseconds per iteration for the blocks this rank owns (0 elsewhere); needs profiled iterations."""

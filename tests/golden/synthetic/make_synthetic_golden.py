@@ -35,6 +35,20 @@ def main():
     print(f"{cfg}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total} p={c['precision']} threads={o.threads} "
           f"setup {time.time() - t0:.0f}s", flush=True)
     recs, secs = [], []
+    name = cfg if scale == 1.0 else f"{cfg}_x{scale}"
+
+    def write():
+        # rewritten after every iteration: a long run that is cut short keeps what it has
+        out = {"config": cfg, "scale": scale, "J": sdp.J, "N": sdp.N, "P_tot": sdp.P_total,
+               "precision": c["precision"], "seed": c["seed"], "params": parity.DEFAULT_PARAMS,
+               "generator": "tests/golden/synthetic/make_synthetic_golden.py (oracle/sdpb_oracle.cpp)",
+               "oracle_threads": o.threads, "oracle_seconds_per_iteration": [round(s, 1) for s in secs],
+               "iterations": recs}
+        tmp = os.path.join(HERE, f".{name}.json.tmp")
+        with open(tmp, "w") as f:
+            json.dump(out, f, indent=1)
+        os.replace(tmp, os.path.join(HERE, f"{name}.json"))
+
     for it in range(iters):
         t = time.time()
         assert not o.iterate(), o.terminate_reason
@@ -43,14 +57,7 @@ def main():
         rec["iteration"] = it + 1
         recs.append(rec)
         print(f"iteration {it + 1}: {secs[-1]:.0f}s  P-obj={rec['P-obj'][:30]}", flush=True)
-    name = cfg if scale == 1.0 else f"{cfg}_x{scale}"
-    out = {"config": cfg, "scale": scale, "J": sdp.J, "N": sdp.N, "P_tot": sdp.P_total,
-           "precision": c["precision"], "seed": c["seed"], "params": parity.DEFAULT_PARAMS,
-           "generator": "tests/golden/synthetic/make_synthetic_golden.py (oracle/sdpb_oracle.cpp)",
-           "oracle_threads": o.threads, "oracle_seconds_per_iteration": [round(s, 1) for s in secs],
-           "iterations": recs}
-    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
-        json.dump(out, f, indent=1)
+        write()
     print("wrote", name)
 
 

@@ -89,3 +89,50 @@ def reference_params(params: dict, oracle) -> dict:
     out = {k: oracle.parse_exact(v, 64) for k, v in full.items()}
     out.update({k: v for k, v in params.items() if k in FLAG_KEYS})
     return out
+
+
+def check_syrk_Q(solver, precision, rows=23, cols=9, seed=3):
+    """The reference's own unit test of syrk_Q (calculate_matrix_square.test.cxx: random P in
+    (-1, 1), Q = P^T P against the plain product, tolerance p/2 bits `:213`), plus the columns that
+    test never produces: a single non-zero NEGATIVE entry, whose normalised value is -1 (or rounds
+    to it) and saturates the fixed-point image."""
+    import random
+    from fractions import Fraction
+    rng = random.Random(seed)
+    P = [[Fraction(rng.randrange(-2 ** 52, 2 ** 52), 2 ** 52) for _ in range(cols)] for _ in range(rows)]
+    # columns 0..3: one non-zero entry each; 0 and 1 share a row (their Q entry is a product of two
+    # saturated values), 3 is positive, the scales differ wildly
+    singles = {0: (4, Fraction(-3)), 1: (4, Fraction(-7, 1024)), 2: (9, Fraction(-1)), 3: (11, Fraction(5, 2 ** 40))}
+    for c, (r, v) in singles.items():
+        for rr in range(rows):
+            P[rr][c] = Fraction(0)
+        P[r][c] = v
+
+    def dec(fr):   # every entry is a dyadic rational: its decimal expansion is finite and exact
+        import decimal
+        with decimal.localcontext() as ctx:
+            ctx.prec = 400
+            return format(decimal.Decimal(fr.numerator) / decimal.Decimal(fr.denominator), "f")
+    colmajor = [dec(P[r][c]) for c in range(cols) for r in range(rows)]
+    got = solver.op_syrk_Q(rows, cols, colmajor)
+    assert len(got) == cols * cols
+    worst = float("-inf")
+    for j in range(cols):
+        for i in range(cols):
+            g = mpmath.mpf(got[i + j * cols])
+            if i < j:
+                assert g == 0
+                continue
+            want = sum(P[r][i] * P[r][j] for r in range(rows))
+            w = mpmath.mpf(want.numerator) / want.denominator
+            if w == 0:
+                # orthogonal columns: exact zero up to the truncation of the image (2^-FB per term)
+                ni = mpmath.sqrt(sum(float(P[r][i]) ** 2 for r in range(rows)))
+                nj = mpmath.sqrt(sum(float(P[r][j]) ** 2 for r in range(rows)))
+                assert abs(g) <= ni * nj * mpmath.mpf(2) ** (-precision + 16), (i, j, got[i + j * cols])
+                continue
+            l2 = log2_rel(g, w)
+            # a random inner product of 23 terms may cancel a few bits; p/2 is the reference's bar
+            assert l2 <= -(precision // 2), (i, j, l2)
+            worst = max(worst, l2)
+    return worst

@@ -60,6 +60,18 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
                 assert got[i + j * cols] == 0
 
 
+@pytest.mark.parametrize("precision", [128, 512, 664, 768, 1024])
+def test_emulated_syrk_Q_stage_and_saturated_columns(precision):
+    """compute_Q.cxx:94-132 as an operator (calculate_matrix_square.test.cxx recipe) incl. columns with
+    a single negative entry: the normalised value saturates the fixed-point image, whose clamp must
+    be 2^FB - 1 for the one-level (664 bits) AND the two-level image (the others)."""
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
+    worst = parity.check_syrk_Q(s, precision)
+    assert worst <= -(precision - 40), worst   # observed: within a few dozen bits of the full mantissa
+    s.close()
+
+
 @pytest.mark.parametrize("name,limit", [("1d-constraints", 5), ("singlet_cT", 3), ("dfibo", None)])
 def test_multi_panel_paths_with_4_column_panels(name, limit):
     """Same sources built with PB = 4: every Cholesky, triangular solve and Q solve of these small
