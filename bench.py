@@ -116,6 +116,51 @@ def cpu_baseline(cfg_name: str, precision: int, seconds_budget: float = 45.0):
                       f"{w_full / w_s:.1f} (MAC model {w_full:.3g}/{w_s:.3g})"}
 
 
+def fixture_path(workload: str, scale: float):
+    name = workload if scale == 1.0 else f"{workload}_x{scale}"
+    return os.path.join(ROOT, "tests", "golden", "synthetic", f"{name}.json")
+
+
+def parity_gate(solver, workload: str, scale: float, precision: int):
+    """"parity gate before any timing counts".  Replays the committed oracle fixture of
+    the selected workload (tests/golden/synthetic/<workload>.json: scalars the GMP oracle produced on
+    the SAME synthetic SDP, tests/golden/synthetic/make_synthetic_golden.py) from the initial point
+    and compares every numeric field of every fixture iteration at relative 2^-(p/2)
+    (calculate_matrix_square.test.cxx:213's convention; the fixture is data, the oracle itself is not
+    called here).  Every rank iterates (the step is collective); every rank compares the same bits.
+    Returns the gate record; the caller refuses to print a value if it failed."""
+    path = fixture_path(workload, scale)
+    if not os.path.exists(path):
+        return {"fixture": None, "passed": None,
+                "note": "no committed oracle fixture for this workload/scale: the value below is NOT parity-gated"}
+    from tests import parity  # comparison helpers only (mpmath); no oracle code
+    with open(path) as f:
+        fx = json.load(f)
+    assert fx["precision"] == precision and fx["N"] == solver.sdp.N and fx["J"] == solver.sdp.J
+    worst, bad_all = float("-inf"), []
+    for rec in fx["iterations"]:
+        if solver.iterate():
+            bad_all.append((rec["iteration"], "terminated: " + solver.terminate_reason))
+            break
+        bad, w = parity.compare_iteration(solver.scalars(), rec, tol_bits=precision // 2)
+        worst = max(worst, w)
+        if bad:
+            bad_all.append((rec["iteration"], bad))
+    return {"fixture": os.path.relpath(path, ROOT), "iterations": len(fx["iterations"]), "tolerance_log2_rel": -(precision // 2),
+            "worst_log2_rel": worst, "passed": not bad_all, "violations": bad_all[:4],
+            "fields": "mu P-obj D-obj gap P-err p-err D-err R-err P-step D-step beta Q_cond_number max_block_cond_number"}
+
+
+def syrk_source_digest() -> str:
+    """Digest of the source region of the dominant kernel (kernels.hpp from the fixed-point image
+    to k_restore_Q): a committed PMC traffic figure is only reported for the build it measured."""
+    import hashlib
+    with open(os.path.join(ROOT, "sdpb_amd", "csrc", "kernels.hpp")) as f:
+        txt = f.read()
+    a, b = txt.find("// Q = P^T P in fixed point"), txt.find("k_restore_Q(")
+    return hashlib.sha1(txt[a:b].encode()).hexdigest()[:16]
+
+
 def _self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one
     rank per GPU (the driver may also launch the ranks itself; then WORLD_SIZE is set and this
@@ -256,6 +301,16 @@ def main():
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(device)
 
+    # parity gate BEFORE anything is timed; then back to the initial point, so the timed
+    # iterations are W+1 .. W+K of the run, as in every earlier round
+    gate = None if sim else parity_gate(solver, args.workload, args.scale, precision)
+    if gate and gate["passed"] is False:
+        if rank == 0:
+            print(json.dumps({"metric": f"interior-point iterations/sec at --precision {precision}", "value": None,
+                              "PARITY_GATE_FAILED": True, "parity_gate": gate}), flush=True)
+        raise SystemExit("bench.py: the device iteration does not reproduce the oracle fixture; no value reported")
+    solver.reset()
+
     for _ in range(args.warmup):
         assert not solver.iterate(), solver.terminate_reason
     timers0 = solver.timers()
@@ -274,6 +329,13 @@ def main():
         dt = float(t.item())
     timers1 = solver.timers()
     syncs1 = solver.host_syncs
+    # proof that N ranks exchanged: what every rank owns and what it handed to the transport
+    mine = {k[5:]: timers1[k] - (timers0.get(k, 0) if k.endswith(("_calls", "_bytes")) else 0) for k in timers1 if k.startswith("comm.")}
+    mine["transport"] = solver.comm_name
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     # per-stage breakdown: one extra, UNTIMED iteration with the stage timers on (they synchronise
     # the stream at every stage boundary, so they are off inside the timed region)
     solver.set_profiling(True)
@@ -296,12 +358,19 @@ def main():
         fb = solver.fx_frac_bits
         fx = (fb + 7) // 32
         k_name = (f"k_syrk_fx2<{fx},32>" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}>") + " (+k_syrk_reduce)"
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_k_syrk_fx.json")
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_k_syrk_fx.json")
         if os.path.exists(pmc) and args.workload == "C4" and args.scale == 1.0 and world == 1:
             with open(pmc) as f:   # rocprofv3 --pmc cannot run inside this process: committed measurement of this command
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        skip = ("kernel.", "host_syncs", "iterations")
+                rec = json.load(f)
+            if rec.get("kernel_source_digest") == syrk_source_digest():
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/pmc_k_syrk_fx.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the "
+                                  f"build with kernel source digest {rec['kernel_source_digest']}, FETCH_SIZE x2 per MI355X_MICROARCH.md)")
+            else:
+                traffic_source = ("dropped: profiles/pmc_k_syrk_fx.json was measured on kernel source digest "
+                                  f"{rec.get('kernel_source_digest')}, this build is {syrk_source_digest()}")
+        skip = ("kernel.", "host_syncs", "iterations", "comm.")
         stages = {k: round(tp1[k] - tp0.get(k, 0.0), 3) for k in tp1 if not k.startswith(skip)}
         nl = solver.limbs
         from sdpb_amd.solver import copy_bandwidth_gbs
@@ -320,10 +389,21 @@ def main():
                        "parallelism": f"blocks sharded over {world} GPU(s); Q' summed by integer all-reduce",
                        "exchange": solver.comm_name},
             "host_syncs_per_step": (syncs1 - syncs0) / args.steps,
+            "parity_gate": gate,
+            # rccl_ranks: size of the RCCL communicator as ncclCommCount reports it on every rank (min over ranks;
+            # 1 for a single GPU, 0 if the exchange ran on callbacks); owned_blocks/rows: the block shard of each rank
+            "rccl_ranks": (min(int(r["ranks"]) for r in per_rank) if all(r["transport"] == "rccl" for r in per_rank)
+                           else (1 if world == 1 else 0)),
+            "exchange_per_rank": {"transport": [r["transport"] for r in per_rank],
+                                  "owned_blocks": [int(r["owned_blocks"]) for r in per_rank],
+                                  "owned_rows": [int(r["owned_rows"]) for r in per_rank],
+                                  "allreduce_calls_per_step": [r["allreduce_calls"] / args.steps for r in per_rank],
+                                  "allreduce_MB_per_step": [round(r["allreduce_bytes"] / args.steps / 1e6, 3) for r in per_rank],
+                                  "allgather_calls_per_step": [r["allgather_calls"] / args.steps for r in per_rank],
+                                  "allgather_MB_per_step": [round(r["allgather_bytes"] / args.steps / 1e6, 3) for r in per_rank]},
             "roofline": {"bound": "hbm", "kernel": k_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r02_pmc_k_syrk_fx.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "command, FETCH_SIZE x2 per MI355X_MICROARCH.md)" if traffic else None,
+                         "traffic_source": traffic_source,
                          "measured_copy_peak": copy_gbs,
                          "launch_ms": 1000.0 * k_avg_s, "algorithmic_bytes_per_launch": k_bytes,
                          "limb_mac_per_s": k_macs / k_avg_s if k_avg_s > 0 else 0.0,

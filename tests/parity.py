@@ -136,3 +136,41 @@ def check_syrk_Q(solver, precision, rows=23, cols=9, seed=3):
             assert l2 <= -(precision // 2), (i, j, l2)
             worst = max(worst, l2)
     return worst
+
+
+def check_c1_at_precision_128(lib_path, n_iter=10):
+    """BASELINE.json config C1 at its STATED precision: the shipped single-correlator SDP
+    (SingletScalar_cT_test_nmax6, J=11, N=20) at --precision 128, first n_iter iterations against
+    the mpf oracle at p=128 (at 128 bits this SDP is under-resolved, so the check is
+    "the first k iterations equal the oracle", not convergence).  Tolerance 2^-(p/2) = 2^-64 on every
+    field but p-err: p = b - B^T x cancels ~85 bits at this precision (terms ~1e26, result ~10), so
+    BOTH implementations carry p to ~2^-15 only; there the bar is the same 2^-64 applied to the
+    cancelling terms (forward error <= conditioning x backward error): |dp| <= 2^-64 max_n sum_p |B_pn x_p|."""
+    from oracle.oracle import Oracle
+    from sdpb_amd.solver import SDPSolver
+    sdp, meta, _, _ = load_case("singlet_cT")
+    o = Oracle(sdp, 128, meta["params"], param_prec=64)
+    s = SDPSolver(sdp, 128, reference_params(meta["params"], o), lib_path=lib_path)
+    assert s.limbs == 6
+    worst = float("-inf")
+    for it in range(n_iter):
+        assert not s.iterate() and not o.iterate(), (it + 1, s.terminate_reason)
+        got, want = s.scalars(), o.scalars()
+        amp = mpmath.mpf(0)
+        xs = [[mpmath.mpf(v) for v in s.array("x", j)] for j in range(sdp.J)]
+        for n in range(sdp.N):
+            t = mpmath.mpf(0)
+            for j, blk in enumerate(sdp.blocks):
+                for pp, row in enumerate(blk.B):
+                    t += abs(mpmath.mpf(row[n]) * xs[j][pp])
+            amp = max(amp, t)
+        dp = abs(mpmath.mpf(got["p-err"]) - mpmath.mpf(want["p-err"]))
+        assert dp <= amp * mpmath.mpf(2) ** -64, (it + 1, float(mpmath.log(dp / amp, 2)))
+        got = dict(got)
+        got["p-err"] = want["p-err"]
+        bad, w = compare_iteration(got, want, tol_bits=64)
+        assert not bad, (it + 1, bad)
+        worst = max(worst, w)
+    s.close()
+    o.close()
+    return worst

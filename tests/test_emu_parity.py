@@ -72,6 +72,12 @@ def test_emulated_syrk_Q_stage_and_saturated_columns(precision):
     s.close()
 
 
+def test_emulated_config_C1_at_its_stated_precision_128():
+    """Whole iterations at 6 limbs (the narrowest compiled width) on the shipped SDP of BASELINE.json's
+    first config; the GPU twin is tests/test_gpu_parity.py::test_config_C1_at_its_stated_precision_128."""
+    assert parity.check_c1_at_precision_128(libs.emu_lib()) <= -64
+
+
 @pytest.mark.parametrize("name,limit", [("1d-constraints", 5), ("singlet_cT", 3), ("dfibo", None)])
 def test_multi_panel_paths_with_4_column_panels(name, limit):
     """Same sources built with PB = 4: every Cholesky, triangular solve and Q solve of these small

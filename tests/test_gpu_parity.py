@@ -36,6 +36,21 @@ def test_device_arithmetic_matches_mpf(precision):
     s.close()
 
 
+# ---- the syrk_Q stage as an operator: calculate_matrix_square.test.cxx recipe + saturated columns
+@pytest.mark.parametrize("precision", [128, 256, 400, 512, 664, 768, 1024])
+def test_syrk_Q_stage_and_saturated_columns(precision):
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    worst = parity.check_syrk_Q(s, precision, rows=70, cols=37)
+    assert worst <= -(precision - 40), worst
+    s.close()
+
+
+# ---- BASELINE.json config C1 at its stated --precision 128 (whole iterations at 6 limbs)
+def test_config_C1_at_its_stated_precision_128():
+    assert parity.check_c1_at_precision_128(libs.product_lib()) <= -64
+
+
 # ---- the dominant kernel: fixed-point syrk is bit exact (integers)
 @pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (512, 300, 50, None), (512, 9, 1, None),
                                                         (1024, 64, 33, None), (512, 300, 50, "4"), (256, 100, 40, "16")])
