@@ -60,6 +60,9 @@ def lib():
         L.orc_get_records.restype = ctypes.c_long
         L.orc_get_records.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_long]
+        L.orc_schur_solver_init.argtypes = [ctypes.c_void_p]
+        L.orc_schur_solve.argtypes = [ctypes.c_void_p]
+        L.orc_set_array.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
         L.orc_set_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
         _lib = L
@@ -172,6 +175,17 @@ class Oracle:
         out = np.zeros((n, 2 + limbs64), dtype=np.uint64)
         self.L.orc_get_records(self.h, which.encode(), j, parity, limbs64, out.ctypes.data_as(ctypes.c_void_p), n)
         return out
+
+    def schur_solver_init(self):
+        """L_j, P_j, Cholesky(Q) from the current X, Y (approx_objective/setup_solver.cxx:204-220)."""
+        self._chk(self.L.orc_schur_solver_init(self.h))
+
+    def schur_solve(self):
+        """solve_schur_complement_equation.cxx:16-79 on the right-hand sides in dx / dy (in place)."""
+        self._chk(self.L.orc_schur_solve(self.h))
+
+    def set_array(self, which: str, values, j: int = 0, parity: int = 0):
+        self._chk(self.L.orc_set_array(self.h, which.encode(), j, parity, " ".join(values).encode()))
 
     @property
     def terminate_reason(self) -> str:

@@ -1675,6 +1675,77 @@ int orc_iterate(void *h, int *terminated)
   ORC_CATCH(o)
 }
 
+// ---- the Schur-solver hook (what approx_objective / outer_limits reuse) ----------
+// approx_objective/setup_solver.cxx:204-220 and outer_limits/compute_optimal/
+// compute_optimal.cxx:188-215 call, on a loaded solution (X, Y):
+//   cholesky_decomposition(X), cholesky_decomposition(Y), compute_bilinear_pairings,
+//   initialize_schur_complement_solver (compute_schur_complement, L_j = chol(S_j),
+//   P_j = L_j^{-1} B_j, Q = sum P_j^T P_j, Cholesky(UPPER, Q))
+// and then solve_schur_complement_equation with their own right-hand sides.  The product
+// exposes that as sdpb_hip_schur_solver_init / sdpb_hip_schur_solve; this is the checker.
+int orc_schur_solver_init(void *h)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  ORC_TRY(o)
+  cholesky_decomposition(*o, true);
+  cholesky_decomposition(*o, false);
+  compute_bilinear_pairings(*o);
+  compute_schur_complement(*o);
+  initialize_schur_off_diagonal(*o);
+  syrk_Q(*o);
+  try
+    {
+      cholesky_upper(o->Q);
+    }
+  catch(NonPD &e)
+    {
+      throw std::runtime_error(std::string("Error when computing Cholesky(Q): ") + e.what());
+    }
+  ORC_CATCH(o)
+}
+// solve_schur_complement_equation.cxx:16-79 with the solver above: in dx (per block) and dy
+// (set with orc_set_array), out the solution in the same arrays
+int orc_schur_solve(void *h)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  ORC_TRY(o)
+  solve_schur_complement_equation(*o);
+  ORC_CATCH(o)
+}
+// which in {"x","X","y","Y","dx","dy"}: column-major decimals (state injection / right-hand sides)
+int orc_set_array(void *h, const char *which, int j, int parity, const char *txt)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  ORC_TRY(o)
+  const std::string w(which);
+  std::vector<F> v;
+  auto into = [&](std::vector<F> &dst) {
+    parse_list(txt, v, dst.size(), which);
+    for(size_t i = 0; i < dst.size(); ++i)
+      dst[i] = v[i];
+  };
+  if(w == "y") into(o->y);
+  else if(w == "dy")
+    {
+      o->dy.resize(o->N);
+      into(o->dy);
+    }
+  else
+    {
+      Block &bl = o->blk.at(j);
+      if(w == "x") into(bl.x);
+      else if(w == "dx")
+        {
+          bl.dx.resize(bl.P);
+          into(bl.dx);
+        }
+      else if(w == "X") into(bl.X[parity ? 1 : 0].a);
+      else if(w == "Y") into(bl.Y[parity ? 1 : 0].a);
+      else throw std::runtime_error("orc_set_array: unknown array " + w);
+    }
+  ORC_CATCH(o)
+}
+
 int orc_terminate_reason(void *h)
 {
   return static_cast<Oracle *>(h)->terminate_reason;

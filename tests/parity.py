@@ -174,3 +174,74 @@ def check_c1_at_precision_128(lib_path, n_iter=10):
     s.close()
     o.close()
     return worst
+
+
+def maxrel(got, want):
+    """log2 of max |got - want| / max |want| over two lists of decimals"""
+    g = [mpmath.mpf(v) for v in got]
+    w = [mpmath.mpf(v) for v in want]
+    assert len(g) == len(w)
+    scale = max(abs(v) for v in w)
+    if scale == 0:
+        return float("-inf") if all(v == 0 for v in g) else 0.0
+    d = max(abs(a - b) for a, b in zip(g, w)) / scale
+    return float(mpmath.log(d, 2)) if d > 0 else float("-inf")
+
+
+def check_schur_hook_against_oracle(lib_path, name="singlet_cT", warm_iterations=3):
+    """SURVEY.md §8f row 4 against the ORACLE (not against the iteration's own solver): from a loaded
+    solution (x, X, y, Y) — what approx_objective/setup_solver.cxx:204-220 and outer_limits/
+    compute_optimal.cxx:188-215 start from — sdpb_hip_schur_solver_init must leave the same
+    schur_complement_cholesky L_j, schur_off_diagonal P_j and Cholesky(Q) as the reference sequence
+    restated in oracle/sdpb_oracle.cpp (orc_schur_solver_init), and sdpb_hip_schur_solve the same
+    solution of solve_schur_complement_equation.cxx:16-79 for arbitrary right-hand sides.
+    Tolerance 2^-(p/2) relative to the largest entry of each array."""
+    import random
+    from oracle.oracle import Oracle
+    from sdpb_amd.solver import SDPSolver
+    sdp, meta, _, _ = load_case(name)
+    p = meta["precision"]
+    o = Oracle(sdp, p, meta["params"], param_prec=64)
+    for _ in range(warm_iterations):
+        assert not o.iterate()
+    s = SDPSolver(sdp, p, reference_params(meta["params"], o), lib_path=lib_path)
+    limbs64 = s.limbs // 2 + 1
+    for j in range(sdp.J):                      # the loaded solution: bit-exact records of the oracle's state
+        s.set_array_mpf("x", o.records("x", j, 0, limbs64), j)
+        for b in (0, 1):
+            s.set_array_mpf("X", o.records("X", j, b, limbs64), j, b)
+            s.set_array_mpf("Y", o.records("Y", j, b, limbs64), j, b)
+    s.set_array_mpf("y", o.records("y", 0, 0, limbs64))
+    s.schur_solver_init()
+    o.schur_solver_init()
+    N, tol, report = sdp.N, -(p // 2), {}
+
+    def lower(v, n):
+        return [v[i + j * n] for j in range(n) for i in range(j, n)]
+    for j in range(sdp.J):
+        P = sdp.num_points[j] * sdp.dims[j] * (sdp.dims[j] + 1) // 2
+        report[("L", j)] = maxrel(lower(s.array("L", j), P), lower(o.array("L", j), P))
+        pt, po = s.array("PT", j), o.array("P", j)   # N x P resp. P x N, column-major
+        report[("P", j)] = maxrel([pt[n + q * N] for n in range(N) for q in range(P)], po)
+    q_dev, q_orc = s.array("Q"), o.array("Q")        # lower factor resp. El::Cholesky(UPPER)
+    report[("chol(Q)",)] = maxrel(lower(q_dev, N), [q_orc[j + i * N] for j in range(N) for i in range(j, N)])
+    rng = random.Random(11)
+    for trial in range(2):
+        for j in range(sdp.J):
+            P = sdp.num_points[j] * sdp.dims[j] * (sdp.dims[j] + 1) // 2
+            rhs = [repr(rng.uniform(-1, 1) * 10.0 ** rng.randint(-3, 3)) for _ in range(P)]
+            s.set_array("dx", rhs, j)
+            o.set_array("dx", rhs, j)
+        rhs = [repr(rng.uniform(-1, 1)) for _ in range(N)]
+        s.set_array("dy", rhs)
+        o.set_array("dy", rhs)
+        s.schur_solve()
+        o.schur_solve()
+        report[("dy", trial)] = maxrel(s.array("dy"), o.array("dy"))
+        for j in range(sdp.J):
+            report[("dx", trial, j)] = maxrel(s.array("dx", j), o.array("dx", j))
+    bad = {k: v for k, v in report.items() if v > tol}
+    assert not bad, bad
+    s.close()
+    o.close()
+    return max(report.values())

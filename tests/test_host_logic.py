@@ -175,6 +175,16 @@ def test_schur_solver_hook_for_approx_objective_on_the_device():
     _schur_hook(libs.product_lib())
 
 
+def test_schur_solver_hook_matches_the_oracle():
+    assert parity.check_schur_hook_against_oracle(libs.emu_lib()) <= -384
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["singlet_cT", "1d-constraints"])
+def test_schur_solver_hook_matches_the_oracle_on_the_device(name):
+    assert parity.check_schur_hook_against_oracle(libs.product_lib(), name) <= -384
+
+
 def test_block_timings_are_written_read_and_balance_the_ranks(tmp_path):
     """the timing run writes <checkpointDir>/block_timings (write_timing.cxx:34-68), the
     next run reads it (read_block_costs.cxx:14-59) and plans the blocks on those costs."""
