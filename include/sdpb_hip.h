@@ -209,15 +209,21 @@ int sdpb_hip_timers(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed)
  * <checkpointDir>/block_timings, one integer per line); the block -> rank plan is the same
  * longest-processing-time greedy on those costs instead of the analytic model (NULL = analytic).
  * sdpb_hip_block_timings: microseconds[num_blocks], per iteration, for the blocks THIS rank owns (0
- * elsewhere: sum over ranks, write_timing.cxx:34-68 writes rank 0's gathered column).  Blocks run batched on
- * the GPU, so the measured stage times of the profiled iterations (sdpb_hip_set_profiling) are
- * apportioned by each stage's operation count — Cholesky(S_j) ~ P_j^3/3, L_j^{-1}B_j ~ P_j^2 N/2, the
- * block's rows of the Q syrk ~ P_j (compute_Q.cxx:40-53, bigint_syrk/Readme.md:325-342).
- * The unit is microseconds (a GPU block costs well under the reference's 1 ms resolution); consumers
- * only use the ratios. */
+ * elsewhere: sum over ranks, write_timing.cxx:34-68 writes rank 0's gathered column).  Like the reference
+ * (compute_Q.cxx:40-53 cholesky_<j> + solve_<j>; the syrk split by block size because all blocks are
+ * processed together, bigint_syrk/Readme.md:325-342) a block's cost is its own Cholesky(S_j) + its own
+ * P_j = L_j^{-1} B_j + its rows' share of the Q syrk.  Blocks run batched on the GPU, so the first two are
+ * MEASURED on the device: while an iteration is profiled (sdpb_hip_set_profiling) every workgroup of
+ * those kernels adds its residence time (100 MHz wall clock) to its block's counter, and the stage's
+ * wall time is divided among the blocks in proportion to the measured times
+ * (sdpb_hip_block_clock_ticks returns the raw counters).
+ * The unit is microseconds (a GPU block costs well under the reference's 1 ms resolution: in ms every
+ * block of the benchmark SDP would read 0 or 1); both readers only use the ratios, and ties between
+ * equally loaded ranks go to the rank holding fewer blocks, so a file full of zeros still spreads out. */
 int sdpb_hip_create_with_costs(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N,
                                int device_id, int rank, int world_size, const long long *block_costs, sdpb_hip_ctx **out);
 int sdpb_hip_block_timings(sdpb_hip_ctx *ctx, long long *microseconds);
+int sdpb_hip_block_clock_ticks(sdpb_hip_ctx *ctx, unsigned long long *cholesky_ticks, unsigned long long *solve_ticks);
 int sdpb_hip_plan_blocks_with_costs(int num_blocks, const long long *block_costs, int world_size, int *owners);
 
 /* Block -> rank plan without a context or a GPU (pure host logic). owners[j] out. */

@@ -380,6 +380,14 @@ int sdpb_hip_block_timings(sdpb_hip_ctx *ctx, long long *microseconds)
     ctx->solver->block_timings(microseconds);
   });
 }
+int sdpb_hip_block_clock_ticks(sdpb_hip_ctx *ctx, unsigned long long *cholesky, unsigned long long *solve)
+{
+  return guarded(ctx, [&] {
+    if(!cholesky || !solve)
+      throw sdpb::SolverError(4, "sdpb_hip_block_clock_ticks: null output");
+    ctx->solver->block_clock_ticks(cholesky, solve);
+  });
+}
 int sdpb_hip_plan_blocks_with_costs(int num_blocks, const long long *block_costs, int world_size, int *owners)
 {
   if(num_blocks <= 0 || !block_costs || !owners || world_size < 1)

@@ -260,6 +260,21 @@ template <int NL> MW_HD void ci_update(CiElem<NL> &el, int k, int n, const uint3
 #ifndef SDPB_CHAIN_PRIO
 #define SDPB_CHAIN_PRIO 3
 #endif
+// Per-block cost measurement (the reference times Cholesky and Trsm of every
+// block: compute_Q.cxx:40-53): while an iteration is profiled, every workgroup of the Schur-stage
+// kernels adds its residence time (constant 100 MHz wall clock) to the counter of the block it
+// works on.  cyc == nullptr (every unprofiled iteration): no clock read, no atomic.
+struct WgClock
+{
+  unsigned long long *slot;
+  unsigned long long t0;
+  __device__ WgClock(unsigned long long *cyc, int idx) : slot(cyc ? cyc + idx : nullptr), t0(cyc ? wall_clock64() : 0ull) {}
+  __device__ ~WgClock()
+  {
+    if(slot && threadIdx.x == 0)
+      atomicAdd(slot, wall_clock64() - t0);
+  }
+};
 MW_HD void raise_chain_priority()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -267,10 +282,11 @@ MW_HD void raise_chain_priority()
     __builtin_amdgcn_s_setprio(SDPB_CHAIN_PRIO);
 #endif
 }
-template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A, Batch invd, Batch Li, int p, int *fail)
+template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A, Batch invd, Batch Li, int p, int *fail, unsigned long long *cyc)
 {
   raise_chain_priority();
   const int q = blockIdx.x;
+  WgClock clk(cyc, q);
   const MatDesc d = A.d[q], dv = invd.d[q], di = Li.d[q];
   const int k0 = PB * p, t = threadIdx.x;
   if(k0 >= d.rows)
@@ -406,10 +422,11 @@ constexpr int TRSM_KC = PB < SDPB_TRSM_KC ? PB : SDPB_TRSM_KC; // columns per LD
 // diagonal block, and zero the part of the panel above it.   grid = (row tiles, batch)
 // row tiles [tile0, tile0 + gridDim.x) (the look-ahead schedule of Cholesky(Q) splits them).
 // The rows of the tile and chunks of KC columns of Li are staged in limb-major LDS.
-template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch A, Batch Li, int p, int tile0)
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch A, Batch Li, int p, int tile0, unsigned long long *cyc)
 {
   constexpr int KC = TRSM_KC, SLN = PB * KC, STN = TR * PB;
   const int q = blockIdx.y;
+  WgClock clk(cyc, q);
   const MatDesc d = A.d[q], di = Li.d[q];
   const int k0 = PB * p;
   if(k0 >= d.rows)
@@ -455,10 +472,11 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch
 // with A21 = rows below panel p, columns of panel p.   grid = (lower tiles, batch)
 // lower tiles [tile0, tile0 + gridDim.x) of the trailing matrix; the two 16 x KC operand
 // chunks of a tile are staged in limb-major LDS
-template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p, int tile0)
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p, int tile0, unsigned long long *cyc)
 {
   constexpr int KC = TRSM_KC, SN = 16 * KC;
   const int q = blockIdx.y;
+  WgClock clk(cyc, q);
   const MatDesc d = A.d[q];
   const int k0 = PB * p;
   if(k0 >= d.rows)
@@ -644,10 +662,11 @@ MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const 
   if(ok)
     mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
 }
-template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p)
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p, unsigned long long *cyc)
 {
   constexpr int KC = TRSM_KC;
   const int q = blockIdx.y;
+  WgClock clk(cyc, q);
   const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
   const int k0 = PB * p;
   if(k0 >= dl.rows)

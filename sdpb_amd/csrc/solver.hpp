@@ -137,15 +137,20 @@ inline std::vector<int> plan_block_owners(const std::vector<int> &dims, const st
   for(int j = 0; j < J; ++j)
     order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  // least loaded rank; ties (a block_timings file may hold many zeros: blocks too small for the
+  // file's resolution) go to the rank with the fewest blocks, so zero-cost blocks spread out
+  // instead of piling up on rank 0
   std::vector<double> load(world, 0.0);
+  std::vector<int> held(world, 0);
   for(int j : order)
     {
       int best = 0;
       for(int r = 1; r < world; ++r)
-        if(load[r] < load[best])
+        if(load[r] < load[best] || (load[r] == load[best] && held[r] < held[best]))
           best = r;
       owner[j] = best;
       load[best] += cost[j];
+      held[best] += 1;
     }
   return owner;
 }
@@ -185,6 +190,7 @@ public:
   virtual int fx_frac_bits() const = 0;
   virtual double bench_op(const std::string &op, int a, int b, int reps) = 0;
   virtual void block_timings(long long *microseconds) = 0;
+  virtual void block_clock_ticks(unsigned long long *cholesky, unsigned long long *solve) = 0;
   // operator-level entry points for parity tests
   virtual std::string op_scalar(const std::string &op, const char *a, const char *b) = 0;
   virtual std::string op_int_syrk(int rows, int cols, const char *ints_colmajor) = 0;
@@ -269,6 +275,10 @@ template <int NL> class Solver : public SolverBase
   DevBuf<int> flags_; // [0..2Jl) chol fail per psd (X) matrix, then Q fail, Q diag fail
   DevBuf<int> flags2_; // chol fail of Y (factored on the side stream concurrently with X)
   DevBuf<int> flags3_; // chol fail of the Schur blocks S_j
+  // Per-block measured cost (kernels.hpp: WgClock): [0, Jl) Cholesky(S_j), [Jl, 2 Jl) P_j = L_j^{-1} B_j, in
+  // ticks of the 100 MHz wall clock summed over the workgroups that worked on the block; accumulated over
+  // the profiled iterations only (compute_Q.cxx:40-53 cholesky_/solve_ timers)
+  DevBuf<unsigned long long> blk_cycles_;
   // Result block (kernels.hpp: XOp): R_COUNT numbers + X_EXTRA words.  Reductions deposit their
   // results here; the host reads the whole block with one copy at each of the three
   // synchronisation points of an iteration (fetch()).
@@ -1054,22 +1064,23 @@ private:
     launch(k_symmetrize<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(A), (int)negate);
   }
   // A = L L^T in place for a batch (lower factor; Li receives the inverted diagonal blocks)
-  void blocked_cholesky(const Batch &A, const Batch &invd, const Batch &Li, int max_n, int *fail, hipStream_t st = nullptr)
+  void blocked_cholesky(const Batch &A, const Batch &invd, const Batch &Li, int max_n, int *fail, hipStream_t st = nullptr,
+                        unsigned long long *cyc = nullptr)
   {
     if(!st)
       st = stream_;
     const int panels = cdiv(max_n, PB);
     for(int p = 0; p < panels; ++p)
       {
-        launch(k_chol_inv_lds<NL>, dim3(A.count), dim3(CI_T), st, A, invd, Li, p, fail);
+        launch(k_chol_inv_lds<NL>, dim3(A.count), dim3(CI_T), st, A, invd, Li, p, fail, cyc);
         const int below = max_n - PB * (p + 1), above = PB * p;
         const int rows = std::max(below, above);
         if(rows > 0)
-          launch(k_chol_panel_solve<NL>, dim3(cdiv(rows, TR), A.count), dim3(WG), st, A, Li, p, 0);
+          launch(k_chol_panel_solve<NL>, dim3(cdiv(rows, TR), A.count), dim3(WG), st, A, Li, p, 0, cyc);
         if(below > 0)
           {
             const unsigned tiles = cdiv(below, 16);
-            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), st, A, p, 0);
+            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), st, A, p, 0, cyc);
           }
       }
   }
@@ -1083,7 +1094,8 @@ private:
   {
     const int panels = cdiv(n, PB);
     constexpr int STRIP_ROW_TILES = PB / TR, STRIP_TILES = (PB / 16) * (PB / 16 + 1) / 2;
-    launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, 0, fail);
+    unsigned long long *const cyc = nullptr; // Q is not an SDP block
+    launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, 0, fail, cyc);
     for(int p = 0; p < panels; ++p)
       {
         // here: diagonal block p is queued on st, and st has joined the bulk of step p-1
@@ -1098,22 +1110,22 @@ private:
         HIP_CHECK(hipEventRecord(ev_la_strip_, st));
         HIP_CHECK(hipStreamWaitEvent(st2, ev_la_strip_, 0));
         if(row_tiles > strip_rows)
-          launch(k_chol_panel_solve<NL>, dim3(row_tiles - strip_rows, 1), dim3(WG), st2, A, Li, p, strip_rows);
+          launch(k_chol_panel_solve<NL>, dim3(row_tiles - strip_rows, 1), dim3(WG), st2, A, Li, p, strip_rows, cyc);
         if(ntile > strip_tiles)
-          launch(k_chol_syrk_down<NL>, dim3(ntile - strip_tiles, 1), dim3(WG), st2, A, p, strip_tiles);
+          launch(k_chol_syrk_down<NL>, dim3(ntile - strip_tiles, 1), dim3(WG), st2, A, p, strip_tiles, cyc);
         HIP_CHECK(hipEventRecord(ev_la_bulk_, st2));
         if(strip_tiles > 0) // leading PB x PB block of the trailing update
           launch(k_chol_strip_update<NL>, dim3(cdiv((size_t)PB * (PB + 1) / 2, WG / (PB <= WG ? WG / PB : 1))), dim3(WG), st, A, p);
         if(p + 1 < panels)
-          launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, p + 1, fail); // overlaps the bulk of step p
+          launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, p + 1, fail, cyc); // overlaps the bulk of step p
         HIP_CHECK(hipStreamWaitEvent(st, ev_la_bulk_, 0));
       }
   }
   // X := X L^{-T} (rows of X are the right-hand sides)
-  void trsm_rlt(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n)
+  void trsm_rlt(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n, unsigned long long *cyc = nullptr)
   {
     for(int p = 0; p < (int)cdiv(max_n, PB); ++p)
-      launch(k_trsm_rlt_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, p);
+      launch(k_trsm_rlt_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, p, cyc);
   }
   // X := X L^{-1}
   void trsm_rln(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n)
@@ -1307,14 +1319,14 @@ private:
     {
       // compute_Q.cxx:9-61 : L = chol(S) in place, P^T = B^T L^{-T}
       Timer t(this, "initializeSchurComplementSolver.Q.cholesky");
-      blocked_cholesky(schurB(), vecPB(invdS_), Batch{LiS_.ptr(), d_schur_.p, Jl_}, max_P_, flags3_.p);
+      blocked_cholesky(schurB(), vecPB(invdS_), Batch{LiS_.ptr(), d_schur_.p, Jl_}, max_P_, flags3_.p, nullptr, block_clock(0));
       if(Jl_)
         launch(k_fail_tags<0>, dim3(cdiv(Jl_, WG)), dim3(WG), stream_, (const int *)flags3_.p, Jl_, (unsigned)FAIL_S, 1, d_blk_.p, xwords() + XW_FAIL);
     }
     {
       Timer t(this, "initializeSchurComplementSolver.Q.solve");
       copy(BT_, PT_);
-      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_);
+      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, block_clock(1));
     }
     // Optional (off, see overlap_syrk_): with one rank the whole Q chain — norms, fixed-point image,
     // syrk, restore, Cholesky(Q) — can run on the side stream while the main stream goes on to the
@@ -1370,6 +1382,17 @@ private:
     }
     if(!side)
       cholesky_Q_async();
+  }
+  unsigned long long *block_clock(int stage)
+  {
+    if(!profile_ || !Jl_)
+      return nullptr;
+    if(blk_cycles_.n < (size_t)2 * Jl_)
+      {
+        blk_cycles_.alloc((size_t)2 * Jl_);
+        HIP_CHECK(hipMemsetAsync(blk_cycles_.p, 0, blk_cycles_.n * sizeof(unsigned long long), stream_));
+      }
+    return blk_cycles_.p + (size_t)stage * Jl_;
   }
   // norms^2 -> norms (in place) and 1/norm (Matrix_Normalizer.cxx:133-136); a zero column keeps 0
   void norms_to_inverse(mw::Ptr nr, mw::Ptr inv, size_t n)
@@ -2013,10 +2036,14 @@ public:
   }
 
   // Per-block cost in microseconds per iteration, the quantity the reference measures into
-  // block_timings (compute_Q.cxx:40-53 per-block Cholesky + solve, plus the block's share of the
-  // syrk, bigint_syrk/Readme.md:325-342).  Blocks run batched on the GPU, so the measured STAGE
-  // times of the profiled iterations (sdpb_hip_set_profiling) are apportioned to the local blocks
-  // by each stage's operation count; blocks of other ranks get 0 (the caller sums over ranks).
+  // block_timings: the block's own Cholesky and Trsm (compute_Q.cxx:40-53 cholesky_<j> + solve_<j>)
+  // plus its share of the syrk, which the reference too can only split by block size because all
+  // blocks are processed together (bigint_syrk/Readme.md:325-342).  Blocks run batched on the GPU, so
+  // "the time of block j" is measured as the residence time of the workgroups that worked on it
+  // (kernels.hpp: WgClock, 100 MHz wall clock, profiled iterations only); the measured wall time of
+  // the stage is divided among the local blocks in proportion to those MEASURED times — a block that
+  // is cheaper than its size suggests (zeros short-cut the multi-word products) shows up as cheaper.
+  // Blocks of other ranks get 0 (the caller sums over ranks).
   void block_timings(long long *us) override
   {
     for(int j = 0; j < J_; ++j)
@@ -2026,27 +2053,42 @@ public:
       return it == timers_ms_.end() ? 0.0 : it->second;
     };
     const double t_chol = stage("initializeSchurComplementSolver.Q.cholesky"), t_solve = stage("initializeSchurComplementSolver.Q.solve"),
-                 t_syrk = stage("initializeSchurComplementSolver.Q.syrk"), t_step = stage("step"), t_total = stage("iteration");
-    if(profiled_iterations_ == 0 || t_total <= 0)
+                 t_syrk = stage("initializeSchurComplementSolver.Q.syrk");
+    if(profiled_iterations_ == 0 || stage("iteration") <= 0)
       throw SolverError(4, "block_timings: no profiled iteration yet (sdpb_hip_set_profiling, then iterate)");
-    const double t_rest = std::max(0.0, t_total - t_chol - t_solve - t_syrk);
-    (void)t_step;
-    double s_chol = 0, s_solve = 0, s_syrk = 0, s_rest = 0;
-    std::vector<double> w_chol(Jl_), w_solve(Jl_), w_syrk(Jl_), w_rest(Jl_);
+    if(!Jl_)
+      return;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const std::vector<unsigned long long> cyc = blk_cycles_.download();
+    if(cyc.size() < (size_t)2 * Jl_)
+      throw SolverError(4, "block_timings: the profiled iterations did not reach the Schur complement stage");
+    double s_chol = 0, s_solve = 0, s_rows = 0;
     for(int l = 0; l < Jl_; ++l)
       {
-        const BlockDesc &bd = blk_[l];
-        const double P = bd.P, n0 = bd.n[0], n1 = bd.n[1];
-        s_chol += w_chol[l] = P * P * P / 3;
-        s_solve += w_solve[l] = P * P * (double)N_ / 2;
-        s_syrk += w_syrk[l] = P;
-        s_rest += w_rest[l] = 30 * (n0 * n0 * n0 + n1 * n1 * n1) + 8 * P * P + 6 * P * (double)N_;
+        s_chol += (double)cyc[l];
+        s_solve += (double)cyc[Jl_ + l];
+        s_rows += blk_[l].P;
       }
     for(int l = 0; l < Jl_; ++l)
       {
-        const double ms = t_chol * w_chol[l] / s_chol + t_solve * w_solve[l] / s_solve + t_syrk * w_syrk[l] / s_syrk
-                          + t_rest * w_rest[l] / s_rest;
+        const double ms = (s_chol > 0 ? t_chol * (double)cyc[l] / s_chol : 0.0) + (s_solve > 0 ? t_solve * (double)cyc[Jl_ + l] / s_solve : 0.0)
+                          + t_syrk * blk_[l].P / s_rows;
         us[local_[l]] = (long long)std::llround(1000.0 * ms / (double)profiled_iterations_);
+      }
+  }
+  // the raw counters behind block_timings (tests): ticks of Cholesky(S_j) and of P_j = L_j^{-1} B_j per local block
+  void block_clock_ticks(unsigned long long *cholesky, unsigned long long *solve) override
+  {
+    for(int j = 0; j < J_; ++j)
+      cholesky[j] = solve[j] = 0;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if(blk_cycles_.n < (size_t)2 * Jl_ || !Jl_)
+      return;
+    const std::vector<unsigned long long> cyc = blk_cycles_.download();
+    for(int l = 0; l < Jl_; ++l)
+      {
+        cholesky[local_[l]] = cyc[l];
+        solve[local_[l]] = cyc[Jl_ + l];
       }
   }
 

@@ -76,6 +76,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_create_with_costs.argtypes = [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ll_p, ctypes.POINTER(ctypes.c_void_p)]
     L.sdpb_hip_block_timings.argtypes = [ctypes.c_void_p, ll_p]
+    L.sdpb_hip_block_clock_ticks.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
     L.sdpb_hip_plan_blocks_with_costs.argtypes = [ctypes.c_int, ll_p, ctypes.c_int, c_int_p]
     L.sdpb_hip_destroy.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_destroy.restype = None
@@ -171,9 +172,9 @@ class SDPSolver:
         self.rank, self.world_size = rank, world_size
         J = sdp.J
         h = ctypes.c_void_p()
-        costs = (ctypes.c_longlong * J)(*[int(c) for c in block_costs]) if block_costs is not None else None
         if block_costs is not None and len(block_costs) != J:   # read_block_costs.cxx:50-55
             raise SDPBError(4, f"Incompatible number of entries in block_timings: expected {J} but found {len(block_costs)}")
+        costs = (ctypes.c_longlong * J)(*[int(c) for c in block_costs]) if block_costs is not None else None
         rc = self.L.sdpb_hip_create_with_costs(precision, J, (ctypes.c_int * J)(*sdp.dims),
                                                (ctypes.c_int * J)(*sdp.num_points), sdp.N, device, rank, world_size,
                                                costs, ctypes.byref(h))
@@ -393,6 +394,14 @@ class SDPSolver:
         out = (ctypes.c_longlong * self.sdp.J)()
         self._chk(self.L.sdpb_hip_block_timings(self.h, out))
         return list(out)
+
+    def block_clock_ticks(self):
+        """Raw per-block counters behind block_timings: (cholesky, solve) ticks of the 100 MHz device clock summed
+        over the workgroups that worked on each block during the profiled iterations (0 for other ranks' blocks)."""
+        J = self.sdp.J
+        a, b = (ctypes.c_ulonglong * J)(), (ctypes.c_ulonglong * J)()
+        self._chk(self.L.sdpb_hip_block_clock_ticks(self.h, a, b))
+        return list(a), list(b)
 
     def bench_op(self, op: str, a: int, b: int, reps: int = 3) -> float:
         """Average HIP-event time (ms) of one kernel of the iteration on synthetic operands."""

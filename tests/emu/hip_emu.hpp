@@ -199,6 +199,12 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 void __syncthreads();
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+// the device's constant-rate wall clock (100 MHz on the GPU; here: 10 ns ticks of the host's steady clock)
+inline unsigned long long wall_clock64()
+{
+  return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10ull;
+}
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicMax(int *p, int v)
 {
