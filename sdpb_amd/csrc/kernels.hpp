@@ -1468,8 +1468,30 @@ template <int FX> constexpr bool fx_two_level()
   return FX % 4 == 0 && FX <= 32;
 #endif
 }
-template <int FX> constexpr int fx_planes() { return fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2); }
-template <int FX> constexpr int fx_frac_bits() { return fx_two_level<FX>() ? 32 * FX - 7 : 32 * FX - 3; }
+// TOOM-4 (fx_toom4<FX>(): FX = 16 and 24, i.e. --precision 512 and 768):
+// a' = a0 + a1 b + a2 b^2 + a3 b^3 with pieces of w = 32 M2 - 4 bits (b = 2^w, M2 = FX/4) is
+// evaluated at the seven points 0, 1, -1, 2, -2, 1/2, inf; the product polynomial of a row pair has
+// seven coefficients, so SEVEN products of M2 x M2 limbs per row pair (7/16 of the plain product)
+// replace the nine of the two Karatsuba levels.  The evaluations are linear, hence the sums over the
+// rows of the seven products ARE the evaluations of sum_r a_r(x) b_r(x), and the interpolation (exact
+// integer divisions by 2, 3, 4, 9, 15: GMP's toom_interpolate_7pts sequence) runs once per output
+// element after the row loop (k_syrk4_finish).  Every stored piece is a non-negative integer below
+// 2^(32 M2): the evaluations at -1 and -2 are stored with a bias (K1 = 2 b, K2 = 10 b) that the
+// finish kernel removes exactly with the column sums.  The four spare bits per piece are the
+// headroom of p(2) < 15 b, which costs 17 bits of the image: FB = 4 w - 1 = 32 FX - 17 (495
+// fraction bits at --precision 512, where two Karatsuba levels keep 505 and the reference 512).
+// Image: seven M2-limb pieces per element, piece-major like the two-level image, group g =
+//   0: a0   1: p(1)   2: p(-1) + K1   3: p(2)   4: p(-2) + K2   5: 8 p(1/2)   6: a3.
+template <int FX> constexpr bool fx_toom4()
+{
+#if defined(SDPB_SYRK_ONE_LEVEL) || defined(SDPB_SYRK_NO_TOOM4)
+  return false;
+#else
+  return FX % 4 == 0 && FX >= 16 && FX <= 24; // 512 and 768 bits: below, 17 bits are too large a share of the image
+#endif
+}
+template <int FX> constexpr int fx_planes() { return fx_toom4<FX>() ? 7 * (FX / 4) : fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2); }
+template <int FX> constexpr int fx_frac_bits() { return fx_toom4<FX>() ? 32 * FX - 17 : fx_two_level<FX>() ? 32 * FX - 7 : 32 * FX - 3; }
 
 // out = (x >> BIT0) mod 2^NB as OUT limbs (compile-time positions)
 template <int BIT0, int NB, int W, int OUT> MW_HD void bits_slice(const uint32_t (&x)[W], uint32_t (&out)[OUT])
@@ -1516,11 +1538,17 @@ template <int W, int A> MW_HD void add_shifted(uint32_t (&w)[W], const uint32_t 
 
 // write the 3M planes of one element from sign + FX-limb magnitude (|v| < 2^FB)
 template <int FX> MW_HD void fx_store2(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx);
+template <int FX> MW_HD void fx_store4(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx);
 template <int FX> MW_HD void fx_store(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
 {
   constexpr int M = FX / 2;
   static_assert(FX % 2 == 0 && FX >= 4, "FX = NL - 2 is even");
-  if constexpr(fx_two_level<FX>())
+  if constexpr(fx_toom4<FX>())
+    {
+      fx_store4<FX>(mag, negative, fx, fx_stride, idx);
+      return;
+    }
+  else if constexpr(fx_two_level<FX>())
     {
       fx_store2<FX>(mag, negative, fx, fx_stride, idx);
       return;
@@ -1613,6 +1641,235 @@ template <int FX> MW_HD void fx_store2(const uint32_t (&mag)[FX], bool negative,
           ot[i] = (uint32_t)t;
         }
     }
+}
+
+// ---- Toom-4 image and the signed multi-limb helpers of its interpolation ------------------
+// out = sum_k c_k p_k for small non-negative c_k (no overflow by construction: < 2^(32 M2))
+template <int M2> MW_HD void toom_lin(uint32_t (&out)[M2], const uint32_t (&p)[4][M2], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+{
+  uint64_t cy = 0;
+#pragma unroll
+  for(int i = 0; i < M2; ++i)
+    {
+      // four 32 x 4-bit products and a carry: below 2^38
+      const uint64_t t = (uint64_t)p[0][i] * c0 + (uint64_t)p[1][i] * c1 + (uint64_t)p[2][i] * c2 + (uint64_t)p[3][i] * c3 + cy;
+      out[i] = (uint32_t)t;
+      cy = t >> 32;
+    }
+}
+// seven-piece image of one element (|v| < 2^FB, FB = 32 FX - 17)
+template <int FX> MW_HD void fx_store4(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
+{
+  constexpr int M2 = FX / 4, WB = 32 * M2 - 4, FB = fx_frac_bits<FX>();
+  static_assert(FB == 4 * WB - 1 && FB / 32 == FX - 1, "a' = v + 2^FB fills four pieces of WB bits");
+  uint32_t a[FX];
+  uint64_t borrow = 0;
+#pragma unroll
+  for(int i = 0; i < FX; ++i)
+    {
+      const uint32_t c = (i == FX - 1) ? (1u << (FB % 32)) : 0u;
+      if(negative)
+        {
+          const uint64_t d = (uint64_t)c - (uint64_t)mag[i] - borrow;
+          a[i] = (uint32_t)d;
+          borrow = (d >> 63) & 1u;
+        }
+      else
+        a[i] = mag[i] | c;
+    }
+  uint32_t p[4][M2];
+  bits_slice<0, WB>(a, p[0]);
+  bits_slice<WB, WB>(a, p[1]);
+  bits_slice<2 * WB, WB>(a, p[2]);
+  bits_slice<3 * WB, WB>(a, p[3]);
+  uint32_t e[7][M2];
+#pragma unroll
+  for(int i = 0; i < M2; ++i)
+    {
+      e[0][i] = p[0][i];
+      e[6][i] = p[3][i];
+    }
+  toom_lin<M2>(e[1], p, 1, 1, 1, 1);
+  toom_lin<M2>(e[3], p, 1, 2, 4, 8);
+  toom_lin<M2>(e[5], p, 8, 4, 2, 1);
+  {
+    // p(-1) + 2 b and p(-2) + 10 b: positive part (+ bias) minus negative part, never below zero
+    uint32_t pos[M2], neg[M2];
+    toom_lin<M2>(pos, p, 1, 0, 1, 0);
+    toom_lin<M2>(neg, p, 0, 1, 0, 1);
+    pos[M2 - 1] += 2u << 28; // 2 b = 2^(WB+1): bit 29 of the top limb
+    uint64_t bw = 0;
+#pragma unroll
+    for(int i = 0; i < M2; ++i)
+      {
+        const uint64_t t = (uint64_t)pos[i] - (uint64_t)neg[i] - bw;
+        e[2][i] = (uint32_t)t;
+        bw = (t >> 63) & 1u;
+      }
+    toom_lin<M2>(pos, p, 1, 0, 4, 0);
+    toom_lin<M2>(neg, p, 0, 2, 0, 8);
+    pos[M2 - 1] += 10u << 28; // 10 b
+    bw = 0;
+#pragma unroll
+    for(int i = 0; i < M2; ++i)
+      {
+        const uint64_t t = (uint64_t)pos[i] - (uint64_t)neg[i] - bw;
+        e[4][i] = (uint32_t)t;
+        bw = (t >> 63) & 1u;
+      }
+  }
+#pragma unroll
+  for(int g = 0; g < 7; ++g)
+    {
+      uint32_t *o = fx + ((size_t)g * fx_stride + idx) * M2;
+#pragma unroll
+      for(int i = 0; i < M2; ++i)
+        o[i] = e[g][i];
+    }
+}
+// Z-limb two's-complement integers (Z = 2 M2 + 2: a sum over < 2^32 rows of products of two
+// M2-limb pieces, times the small factors of the interpolation, with a sign)
+template <int Z> MW_HD void z_add(uint32_t (&d)[Z], const uint32_t (&x)[Z])
+{
+  uint64_t cy = 0;
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      const uint64_t t = (uint64_t)d[k] + x[k] + cy;
+      d[k] = (uint32_t)t;
+      cy = t >> 32;
+    }
+}
+template <int Z> MW_HD void z_sub(uint32_t (&d)[Z], const uint32_t (&x)[Z])
+{
+  uint64_t bw = 0;
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      const uint64_t t = (uint64_t)d[k] - (uint64_t)x[k] - bw;
+      d[k] = (uint32_t)t;
+      bw = (t >> 63) & 1u;
+    }
+}
+// d += c x  /  d -= c x  for a small constant c (two's complement in, two's complement out)
+template <int Z> MW_HD void z_addmul(uint32_t (&d)[Z], const uint32_t (&x)[Z], uint32_t c, bool subtract)
+{
+  uint32_t t[Z];
+  uint64_t cy = 0;
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      const uint64_t u = (uint64_t)x[k] * c + cy;
+      t[k] = (uint32_t)u;
+      cy = u >> 32;
+    }
+  if(subtract)
+    z_sub<Z>(d, t);
+  else
+    z_add<Z>(d, t);
+}
+template <int Z> MW_HD void z_sar(uint32_t (&d)[Z], int bits) // exact halvings: arithmetic shift right by 1 or 2
+{
+  const uint32_t fill = 0u - (d[Z - 1] >> 31);
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      const uint32_t up = k + 1 < Z ? d[k + 1 < Z ? k + 1 : 0] : fill;
+      d[k] = (d[k] >> bits) | (up << (32 - bits));
+    }
+}
+template <int Z> MW_HD void z_shl(uint32_t (&d)[Z], int sh) // d <<= sh (0 <= sh < 32 Z)
+{
+  const int q = sh >> 5, r = sh & 31;
+  uint32_t t[Z];
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for(int u = 0; u < Z; ++u)
+        {
+          hi = (u == k - q) ? d[u] : hi;
+          lo = (u == k - q - 1) ? d[u] : lo;
+        }
+      t[k] = r ? ((hi << r) | (lo >> (32 - r))) : hi;
+    }
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    d[k] = t[k];
+}
+// d /= c for an odd constant c that divides d exactly (c^-1 mod 2^32 given): the quotient of a
+// two's-complement value comes out in two's complement (arithmetic modulo 2^(32 Z))
+template <int Z> MW_HD void z_divexact(uint32_t (&d)[Z], uint32_t c, uint32_t cinv)
+{
+  uint32_t carry = 0;
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      const uint32_t b = d[k] < carry ? 1u : 0u;
+      const uint32_t q = (d[k] - carry) * cinv;
+      d[k] = q;
+      carry = (uint32_t)(((uint64_t)q * c) >> 32) + b;
+    }
+}
+// The interpolation of GMP's mpn_toom_interpolate_7pts (points 0, -2, 1, -1, 2, 1/2 (x 64), inf in
+// w[0..6]); on return w[k] is coefficient k of the product polynomial.  Checked against plain
+// integer polynomial products in tests (bit-exact syrk vs GMP mpz).
+template <int Z> MW_HD void toom4_interpolate(uint32_t (&w)[7][Z])
+{
+  z_add<Z>(w[5], w[4]);                 // W5 += W4
+  {                                     // W1 = (W4 - W1) / 2
+    uint32_t t[Z];
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      t[k] = w[4][k];
+    z_sub<Z>(t, w[1]);
+    z_sar<Z>(t, 1);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      w[1][k] = t[k];
+  }
+  z_sub<Z>(w[4], w[0]);                 // W4 -= W0
+  z_sub<Z>(w[4], w[1]);                 // W4 = (W4 - W1) / 4 - 16 W6
+  z_sar<Z>(w[4], 2);
+  z_addmul<Z>(w[4], w[6], 16, true);
+  {                                     // W3 = (W2 - W3) / 2
+    uint32_t t[Z];
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      t[k] = w[2][k];
+    z_sub<Z>(t, w[3]);
+    z_sar<Z>(t, 1);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      w[3][k] = t[k];
+  }
+  z_sub<Z>(w[2], w[3]);                 // W2 -= W3
+  z_addmul<Z>(w[5], w[2], 65, true);    // W5 -= 65 W2
+  z_sub<Z>(w[2], w[6]);                 // W2 -= W6 + W0
+  z_sub<Z>(w[2], w[0]);
+  z_addmul<Z>(w[5], w[2], 45, false);   // W5 = (W5 + 45 W2) / 2
+  z_sar<Z>(w[5], 1);
+  z_sub<Z>(w[4], w[2]);                 // W4 = (W4 - W2) / 3
+  z_divexact<Z>(w[4], 3, 0xAAAAAAABu);
+  z_sub<Z>(w[2], w[4]);                 // W2 -= W4
+  {                                     // W1 = W5 - W1
+    uint32_t t[Z];
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      t[k] = w[5][k];
+    z_sub<Z>(t, w[1]);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      w[1][k] = t[k];
+  }
+  z_addmul<Z>(w[5], w[3], 8, true);     // W5 = (W5 - 8 W3) / 9
+  z_divexact<Z>(w[5], 9, 0x38E38E39u);
+  z_sub<Z>(w[3], w[5]);                 // W3 -= W5
+  z_divexact<Z>(w[1], 15, 0xEEEEEEEFu); // W1 = (W1 / 15 + W5) / 2
+  z_add<Z>(w[1], w[5]);
+  z_sar<Z>(w[1], 1);
+  z_sub<Z>(w[5], w[1]);                 // W5 -= W1
 }
 
 // fx[idx] = image of trunc(PT[idx] * inv_norm[idx % N] * 2^FB)
@@ -2087,7 +2344,8 @@ template <int FX> __global__ void __launch_bounds__(WG) k_syrk_reduce(const uint
 // Stage 1: workgroup (x, y) sums row slice y of 64 columns (4 row phases per column, meeting in
 // LDS) into partial[y]; element (slice, u, k, n), u < 4, k < M2 + 2, at
 // ((slice * 4 + u) * (M2 + 2) + k) * N + n.  Stage 2 adds the slices and recombines.
-template <int FX>
+// (TOOM: the same sums over the groups a0, p(1), p(2), a3 of the Toom-4 image, k_fx_colsum4_final)
+template <int FX, bool TOOM = false>
 __global__ void __launch_bounds__(WG) k_fx_colsum2(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, unsigned rows_per_slice, uint32_t *partial)
 {
   constexpr int M2 = FX / 4, A = M2 + 2;
@@ -2106,7 +2364,8 @@ __global__ void __launch_bounds__(WG) k_fx_colsum2(const uint32_t *fx, size_t fx
 #pragma unroll
         for(int u = 0; u < 4; ++u)
           {
-            const uint32_t *src = fx + ((size_t)(u < 2 ? u : u + 1) * fx_stride + e) * M2;
+            const int grp = TOOM ? (u == 0 ? 0 : u == 1 ? 1 : u == 2 ? 3 : 6) : (u < 2 ? u : u + 1);
+            const uint32_t *src = fx + ((size_t)grp * fx_stride + e) * M2;
             uint64_t cy = 0;
 #pragma unroll
             for(int k = 0; k < A; ++k)
@@ -2185,6 +2444,178 @@ __global__ void __launch_bounds__(WG) k_fx_colsum2_final(const uint32_t *partial
 #pragma unroll
   for(int k = 0; k < W; ++k)
     acc[(size_t)k * acc_stride + (size_t)N * N + col] = w[k];
+}
+
+// Toom-4 image: from the slice sums of the groups a0, p(1), p(2), a3 (k_fx_colsum2<FX, true>)
+//   s0 = sum a0, s3 = sum a3, u = sum p(1) - s0 - s3 = s1 + s2, v = (sum p(2) - s0 - 8 s3)/2 = s1 + 2 s2
+//   S   = s0 + s1 b + s2 b^2 + s3 b^3                      -> behind the N x N block of acc (k_syrk_unbias)
+//   E1  = s0 - s1 + s2 - s3 = sum_r p_r(-1),  E2 = s0 - 2 s1 + 4 s2 - 8 s3 = sum_r p_r(-2)
+//   U1  = K1 E1 + n K1^2 / 2,  U2 = K2 E2 + n K2^2 / 2       -> toomU (Z limbs each; k_syrk4_finish)
+// so that sum_r p_ri(-1) p_rj(-1) = sum_r (p_ri(-1) + K1)(p_rj(-1) + K1) - (U1_i + U1_j): with T = E + n K
+// the stored (biased) pieces sum to T, and K (T_i + T_j) - n K^2 = K (E_i + E_j) + n K^2 = U_i + U_j.
+// n = the rows of THIS rank (the bias of the stored pieces is removed before any cross-GPU sum).
+template <int FX>
+__global__ void __launch_bounds__(WG)
+  k_fx_colsum4_final(const uint32_t *partial, int nslices, int N, uint32_t *acc, size_t acc_stride, uint32_t *toomU, unsigned long long nrows_local)
+{
+  constexpr int M2 = FX / 4, A = M2 + 2, W = 2 * FX + 2, WB = 32 * M2 - 4, Z = 2 * M2 + 2;
+  const int col = blockIdx.x * WG + threadIdx.x;
+  if(col >= N)
+    return;
+  uint32_t sum[4][A];
+#pragma unroll
+  for(int u = 0; u < 4; ++u)
+#pragma unroll
+    for(int k = 0; k < A; ++k)
+      sum[u][k] = 0;
+  for(int s = 0; s < nslices; ++s)
+#pragma unroll
+    for(int u = 0; u < 4; ++u)
+      {
+        uint64_t cy = 0;
+#pragma unroll
+        for(int k = 0; k < A; ++k)
+          {
+            const uint64_t t = (uint64_t)sum[u][k] + partial[(((size_t)s * 4 + u) * A + k) * N + col] + cy;
+            sum[u][k] = (uint32_t)t;
+            cy = t >> 32;
+          }
+      }
+  uint32_t s0[Z], s1[Z], s2[Z], s3[Z], t[Z];
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      s0[k] = k < A ? sum[0][k < A ? k : 0] : 0u;
+      s1[k] = k < A ? sum[1][k < A ? k : 0] : 0u; // sum p(1)
+      s2[k] = k < A ? sum[2][k < A ? k : 0] : 0u; // sum p(2)
+      s3[k] = k < A ? sum[3][k < A ? k : 0] : 0u;
+    }
+  z_sub<Z>(s1, s0); // u = s1 + s2
+  z_sub<Z>(s1, s3);
+  z_sub<Z>(s2, s0); // v = s1 + 2 s2
+  z_addmul<Z>(s2, s3, 8, true);
+  z_sar<Z>(s2, 1);
+  z_sub<Z>(s2, s1); // s2 = v - u
+  z_sub<Z>(s1, s2); // s1 = u - s2
+  uint32_t w[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    w[k] = k < Z ? s0[k < Z ? k : 0] : 0u;
+  add_shifted<W, Z>(w, s1, WB, false);
+  add_shifted<W, Z>(w, s2, 2 * WB, false);
+  add_shifted<W, Z>(w, s3, 3 * WB, false);
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    acc[(size_t)k * acc_stride + (size_t)N * N + col] = w[k];
+  uint32_t n[Z];
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    n[k] = k == 0 ? (uint32_t)nrows_local : k == 1 ? (uint32_t)(nrows_local >> 32) : 0u;
+  // U1 = (E1 << (WB+1)) + (n << (2 WB + 1)),  K1 = 2^(WB+1)
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    t[k] = s0[k];
+  z_sub<Z>(t, s1);
+  z_add<Z>(t, s2);
+  z_sub<Z>(t, s3);
+  z_shl<Z>(t, WB + 1);
+  {
+    uint32_t m[Z];
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      m[k] = n[k];
+    z_shl<Z>(m, 2 * WB + 1);
+    z_add<Z>(t, m);
+  }
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    toomU[(size_t)k * N + col] = t[k];
+  // U2 = (10 E2 << WB) + (50 n << 2 WB),  K2 = 10 2^WB
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    t[k] = s0[k];
+  z_addmul<Z>(t, s1, 2, true);
+  z_addmul<Z>(t, s2, 4, false);
+  z_addmul<Z>(t, s3, 8, true);
+  {
+    uint32_t m[Z];
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      m[k] = 0;
+    z_addmul<Z>(m, t, 10, false);
+    z_shl<Z>(m, WB);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      t[k] = 0;
+    z_addmul<Z>(t, n, 50, false);
+    z_shl<Z>(t, 2 * WB);
+    z_add<Z>(t, m);
+  }
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    toomU[(size_t)(Z + k) * N + col] = t[k];
+}
+// acc(i,j) (i >= j) = G(i,j) = sum_r a'_ri a'_rj from the seven product sums the row splits of
+// k_syrk_fx2<FX, RBG, true> left in part (split s, group g, limb k at ((s 7 + g) A2 + k) acc_stride + idx):
+// add the splits, remove the bias of the two signed evaluation points, interpolate, recombine.
+template <int FX>
+__global__ void __launch_bounds__(WG)
+  k_syrk4_finish(const uint32_t *part, int nsplit, const uint32_t *toomU, uint32_t *acc, size_t acc_stride, int N)
+{
+  constexpr int M2 = FX / 4, A2 = 2 * M2 + 1, Z = 2 * M2 + 2, W = 2 * FX + 2, WB = 32 * M2 - 4;
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)N * N)
+    return;
+  const int i = (int)(idx % N), j = (int)(idx / N);
+  if(i < j)
+    return;
+  uint32_t w[7][Z];
+  // GMP's order: w0 = f(0), w1 = f(-2), w2 = f(1), w3 = f(-1), w4 = f(2), w5 = 64 f(1/2), w6 = f(inf)
+  constexpr int GRP[7] = {0, 4, 1, 2, 3, 5, 6};
+#pragma unroll
+  for(int q = 0; q < 7; ++q)
+    {
+      uint64_t cy = 0;
+#pragma unroll
+      for(int k = 0; k < Z; ++k)
+        {
+          if(k < A2)
+            for(int s = 0; s < nsplit; ++s)
+              cy += part[(((size_t)s * 7 + GRP[q]) * A2 + k) * acc_stride + idx];
+          w[q][k] = (uint32_t)cy;
+          cy >>= 32;
+        }
+    }
+  {
+    uint32_t u[Z];
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      u[k] = toomU[(size_t)k * N + i];
+    z_sub<Z>(w[3], u);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      u[k] = toomU[(size_t)k * N + j];
+    z_sub<Z>(w[3], u);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      u[k] = toomU[(size_t)(Z + k) * N + i];
+    z_sub<Z>(w[1], u);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      u[k] = toomU[(size_t)(Z + k) * N + j];
+    z_sub<Z>(w[1], u);
+  }
+  toom4_interpolate<Z>(w);
+  uint32_t g[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    g[k] = k < Z ? w[0][k < Z ? k : 0] : 0u;
+#pragma unroll
+  for(int q = 1; q < 7; ++q)
+    add_shifted<W, Z>(g, w[q], q * WB, false);
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    acc[(size_t)k * acc_stride + idx] = g[k];
 }
 
 // one M2-limb piece with the widest loads its size allows (pieces are M2*4-byte aligned)
@@ -2292,7 +2723,9 @@ template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
 #ifndef SDPB_SYRK2_UNROLL
 #define SDPB_SYRK2_UNROLL 4 // row loop of the non-prefetching variant
 #endif
-template <int FX, int RBG>
+// TOOM: the seven products of the Toom-4 image instead (one sweep); the seven row sums are written
+// as they are, A2 limbs each, to split * 7 A2 planes of the output, and k_syrk4_finish interpolates.
+template <int FX, int RBG, bool TOOM = false>
 __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   k_syrk_fx2(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
              const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, const uint32_t *zero_piece)
@@ -2310,7 +2743,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   const int split = item / ntile, tile = item % ntile;
   const unsigned row_begin = (unsigned)split * rows_per_split;
   const unsigned row_end = (row_begin + rows_per_split < nrows && split + 1 < nsplit) ? row_begin + rows_per_split : nrows;
-  acc += (size_t)split * W * acc_stride;
+  acc += (size_t)split * (TOOM ? 7 * A2 : W) * acc_stride;
   const uint32_t tt = tile_list[tile];
   const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
@@ -2321,9 +2754,9 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   // the register file, else (1024-bit operands: 9 x 18 limbs) the three of one first-level operand
   // at a time — three sweeps, the same passes in another order, each closed by its second-level
   // recombination into x[sweep]
-  constexpr int NG = FX >= 32 ? 3 : 9, SWEEPS = 9 / NG;
+  constexpr int NG = TOOM ? 7 : FX >= 32 ? 3 : 9, SWEEPS = TOOM ? 1 : 9 / NG;
   uint32_t g2[NG][A2];
-  uint32_t x[3][A];
+  uint32_t x[TOOM ? 1 : 3][TOOM ? 1 : A];
   // Staging of the NEXT pass.  16-byte pieces (M2 = 4) go HBM/L2 -> LDS directly
   // (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16 B, exactly the [row][column] piece
   // order), with no staging registers and no ds_write pass; the barrier that ends the pass drains
@@ -2386,6 +2819,10 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   };
   // second level: XX = X0X0 + (XtXt - X0X0 - X1X1) B2 + X1X1 B2^2 for X = first-level operand k
   auto second_level = [&](int k, int g0) __attribute__((always_inline)) {
+    if constexpr(TOOM)
+      return;
+    else
+      {
     sub_limbs<A2>(g2[g0 + 2], g2[g0]);
     sub_limbs<A2>(g2[g0 + 2], g2[g0 + 1]);
 #pragma unroll
@@ -2393,6 +2830,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
       x[k][q] = q < A2 ? g2[g0][q < A2 ? q : 0] : 0u;
     add_shifted<A, A2>(x[k], g2[g0 + 2], 32 * M2 - 1, false);
     add_shifted<A, A2>(x[k], g2[g0 + 1], 64 * M2 - 2, false);
+      }
   };
 #pragma unroll
   for(int sweep = 0; sweep < SWEEPS; ++sweep)
@@ -2461,6 +2899,21 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   if constexpr(SWEEPS == 3)
     second_level(sweep, 0);
   }
+  if constexpr(TOOM)
+    {
+      if(i < N && j <= i)
+        {
+          const size_t o = (size_t)i + (size_t)j * N;
+#pragma unroll
+          for(int g = 0; g < 7; ++g)
+#pragma unroll
+            for(int k = 0; k < A2; ++k)
+              acc[(size_t)(g * A2 + k) * acc_stride + o] = g2[g][k];
+        }
+      return;
+    }
+  else
+  {
   if constexpr(SWEEPS == 1)
     {
 #pragma unroll
@@ -2483,6 +2936,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
       for(int k = 0; k < W; ++k)
         acc[(size_t)k * acc_stride + o] = w[k];
     }
+  }
 }
 
 // Remove the bias in place (after any cross-GPU sum): for i >= j

@@ -229,7 +229,9 @@ template <int NL> class Solver : public SolverBase
   using M = Mw<NL>;
   static constexpr int FX = NL - 2; // 32*FX = GMP's rounded precision 64*(l-1) (compute_Q.cxx:107)
   static constexpr int ACCW = 2 * FX + 2;
-  static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>(); // nine (FX/4)^2 products per row pair (k_syrk_fx2) instead of three (FX/2)^2
+  static constexpr bool SYRK_TOOM4 = fx_toom4<FX>();         // seven (FX/4)^2 products per row pair (k_syrk_fx2<.., true> + k_syrk4_finish)
+  static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>() || SYRK_TOOM4; // piece-major image: nine (two Karatsuba levels) or seven pieces
+  static constexpr int SYRK_PART_PLANES = SYRK_TOOM4 ? 7 * (2 * (FX / 4) + 1) : ACCW; // planes one row split writes
   // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
 #ifndef SDPB_SYRK2_RBG
 #define SDPB_SYRK2_RBG (FX >= 32 ? 16 : 32)
@@ -267,7 +269,7 @@ template <int NL> class Solver : public SolverBase
   DevArray LiX_, LiY_, LiS_, LiQ_, qtmpv_; // inverted diagonal blocks of the Cholesky factors
   DevArray part2_; // partial sums of the column norms (the Q chain may run beside the predictor, which uses part_)
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, lam2_, ratio_, scal_;
-  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, colsum_partial_, syrk_part_;
+  DevBuf<uint32_t> fx_, acc_, syrk_tiles_, colsum_partial_, syrk_part_, toomU_;
   int num_cus_ = 256;
   unsigned colsum_slices_ = 1;
   DevBuf<double> eigF_, eigF2_;
@@ -613,8 +615,10 @@ private:
       // partial outputs of the row-split syrk (sized once, here, not inside the iteration)
       const unsigned tiles = cdiv(N_, 16);
       const int nsplit = syrk_row_splits((int)(tiles * (tiles + 1) / 2), (unsigned)Ptot_, num_cus_ * syrk_waves_per_simd<FX>(), SYRK_RB);
-      if(nsplit > 1)
-        syrk_part_.alloc((size_t)nsplit * ACCW * acc_stride_);
+      if(nsplit > 1 || SYRK_TOOM4)
+        syrk_part_.alloc((size_t)nsplit * SYRK_PART_PLANES * acc_stride_);
+      if(SYRK_TOOM4)
+        toomU_.alloc((size_t)2 * (2 * (FX / 4) + 2) * N_);
     }
     colsum_slices_ = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv(Ptot_, 64)));
     colsum_partial_.alloc((size_t)colsum_slices_ * (FX + 8) * N_); // 2 (FX/2 + 2) or 4 (FX/4 + 2) limbs per column and slice
@@ -714,8 +718,9 @@ public:
     ss << (first ? "" : ", ") << "\"kernel.k_syrk_fx.ms\": " << syrk_kernel_ms_ << ", \"kernel.k_syrk_fx.launches\": " << syrk_launches_
        << ", \"kernel.k_syrk_fx.algorithmic_bytes\": " << (fx_bytes + acc_bytes)
        << ", \"kernel.k_syrk_fx.limb_macs\": "
-       << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 9 (FX/4)^2 or 3 (FX/2)^2 per product
-       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TWO_LEVEL ? 2 : 1) << ", \"host_syncs\": " << host_syncs_
+       << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TOOM4 ? 7.0 / 16 : SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 7 or 9 (FX/4)^2, or 3 (FX/2)^2 per product
+       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TOOM4 ? 0 : SYRK_TWO_LEVEL ? 2 : 1) << ", \"kernel.k_syrk_fx.toom4\": " << (SYRK_TOOM4 ? 1 : 0)
+       << ", \"host_syncs\": " << host_syncs_
        << ", \"iterations\": " << iteration_ << ", \"comm.world\": " << world_ << ", \"comm.ranks\": " << (comm_ ? comm_->ranks() : (world_ == 1 ? 1 : 0))
        << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
        << ", \"comm.allgather_bytes\": " << xc_allgather_bytes_ << ", \"comm.allreduce_calls\": " << xc_allreduce_calls_
@@ -1354,12 +1359,12 @@ private:
       const unsigned tiles = cdiv(N_, 16);
       if(cnt)
         {
-          syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_);
+          syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_, toomU_.p);
           // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); they are
           // read back lazily, after a later synchronisation point has passed them
           resolve_syrk_events();
           HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
-          syrk_G(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, (const uint32_t *)syrk_tiles_.p, syrk_part_);
+          syrk_G(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, (const uint32_t *)syrk_tiles_.p, syrk_part_, toomU_.p);
           HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
           syrk_events_pending_ = true;
         }
@@ -1414,21 +1419,31 @@ private:
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
   // that fills the last round of resident workgroups better; `part` grows on demand
   void syrk_G(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tiles_dev,
-              DevBuf<uint32_t> &part)
+              DevBuf<uint32_t> &part, const uint32_t *toomU = nullptr)
   {
+    if(SYRK_TOOM4 && !toomU)
+      throw SolverError(4, "syrk_G: the Toom-4 image needs the column terms of syrk_column_sums");
     const unsigned tiles = cdiv(N, 16);
     const int ntile = (int)(tiles * (tiles + 1) / 2);
     const int slots = num_cus_ * syrk_waves_per_simd<FX>();
     const int nsplit = syrk_row_splits(ntile, nrows, slots, SYRK_RB);
     const unsigned rps = cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB;
     uint32_t *out = acc;
-    if(nsplit > 1)
+    if(nsplit > 1 || SYRK_TOOM4)
       {
-        if(part.n < (size_t)nsplit * ACCW * acc_stride)
-          part.alloc((size_t)nsplit * ACCW * acc_stride);
+        if(part.n < (size_t)nsplit * SYRK_PART_PLANES * acc_stride)
+          part.alloc((size_t)nsplit * SYRK_PART_PLANES * acc_stride);
         out = part.p;
       }
-    if constexpr(SYRK_TWO_LEVEL)
+    if constexpr(SYRK_TOOM4)
+      {
+        launch(k_syrk_fx2<FX, SYRK_RB, true>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out,
+               acc_stride, tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
+        launch(k_syrk4_finish<FX>, dim3(cdiv((size_t)N * N, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, (const uint32_t *)toomU, acc,
+               acc_stride, N);
+        return;
+      }
+    else if constexpr(SYRK_TWO_LEVEL)
       launch(k_syrk_fx2<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
              tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
     else
@@ -1439,10 +1454,19 @@ private:
   }
   // S_n = sum_r a'_rn behind the N x N block of acc (kernels.hpp: k_fx_colsum)
   void syrk_column_sums(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, uint32_t *partial,
-                        unsigned slices)
+                        unsigned slices, uint32_t *toomU = nullptr)
   {
     const unsigned rows_per_slice = cdiv(nrows, slices);
-    if constexpr(SYRK_TWO_LEVEL)
+    if constexpr(SYRK_TOOM4)
+      {
+        if(!toomU)
+          throw SolverError(4, "syrk_column_sums: the Toom-4 image needs a buffer for its column terms");
+        launch(k_fx_colsum2<FX, true>, dim3(cdiv(N, 64), slices), dim3(WG), stream_, fx, fx_stride, nrows, N, rows_per_slice, partial);
+        launch(k_fx_colsum4_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride, toomU,
+               (unsigned long long)nrows);
+        return;
+      }
+    else if constexpr(SYRK_TWO_LEVEL)
       {
         launch(k_fx_colsum2<FX>, dim3(cdiv(N, 64), slices), dim3(WG), stream_, fx, fx_stride, nrows, N, rows_per_slice, partial);
         launch(k_fx_colsum2_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride);
@@ -2160,10 +2184,13 @@ public:
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
-    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part); // warm-up (sizes `part`)
+    DevBuf<uint32_t> tu; // column terms of the Toom-4 image (zeros: the timing does not depend on them)
+    tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
+    HIP_CHECK(hipMemsetAsync(tu.p, 0, tu.n * sizeof(uint32_t), stream_));
+    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p); // warm-up (sizes `part`)
     HIP_CHECK(hipEventRecord(e0, stream_));
     for(int r = 0; r < std::max(reps, 1); ++r)
-      syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part);
+      syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
     HIP_CHECK(hipEventRecord(e1, stream_));
     HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -2215,9 +2242,11 @@ public:
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
     partial.alloc((size_t)slices * (FX + 8) * cols);
-    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices);
+    DevBuf<uint32_t> tu;
+    tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
+    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
     tl.upload(syrk_tile_order(cols));
-    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, spart);
+    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, spart, tu.p);
     qf.alloc(4);
     HIP_CHECK(hipMemsetAsync(qf.p, 0, 4 * sizeof(int), stream_));
     launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows);
@@ -2285,12 +2314,14 @@ public:
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
     partial.alloc((size_t)slices * (FX + 8) * cols);
-    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices);
+    DevBuf<uint32_t> tu;
+    tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
+    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
     const unsigned tiles = cdiv(cols, 16);
     DevBuf<uint32_t> tl;
     tl.upload(syrk_tile_order(cols));
     DevBuf<uint32_t> part;
-    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part);
+    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
     launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows);
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<uint32_t> a = acc.download();
