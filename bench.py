@@ -356,8 +356,9 @@ def main():
         achieved = k_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         # which instantiation that is: two Karatsuba levels keep 7 spare bits in the image, one level 3
         fb = solver.fx_frac_bits
-        fx = (fb + 7) // 32
-        k_name = (f"k_syrk_fx2<{fx},32>" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}>") + " (+k_syrk_reduce)"
+        fx = solver.limbs - 2
+        k_name = (f"k_syrk_fx2<{fx},32,toom4> (+k_syrk4_finish)" if 32 * fx - 17 == fb else
+                  f"k_syrk_fx2<{fx},32> (+k_syrk_reduce)" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}> (+k_syrk_reduce)")
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_k_syrk_fx.json")
         if os.path.exists(pmc) and args.workload == "C4" and args.scale == 1.0 and world == 1:
@@ -379,7 +380,7 @@ def main():
             "metric": f"interior-point iterations/sec at --precision {precision}",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": f"mw{32 * nl} (fixed-width multi-word float, {nl}x32-bit limbs; Q syrk in {32 * (nl - 2)}-bit fixed point)",
+            "dtype": f"mw{32 * nl} (fixed-width multi-word float, {nl}x32-bit limbs; Q syrk: exact integer product of a fixed-point image with {solver.fx_frac_bits} fraction bits)",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: synthetic "
                                    + ("3d-Ising mixed-correlator" if args.workload == "C4" else "stress" if args.workload.startswith("C5")
