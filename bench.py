@@ -357,8 +357,9 @@ def main():
         # which instantiation that is: two Karatsuba levels keep 7 spare bits in the image, one level 3
         fb = solver.fx_frac_bits
         fx = solver.limbs - 2
-        k_name = (f"k_syrk_fx2<{fx},32,toom4> (+k_syrk4_finish)" if 32 * fx - 17 == fb else
-                  f"k_syrk_fx2<{fx},32> (+k_syrk_reduce)" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}> (+k_syrk_reduce)")
+        rbg = 16 if fx >= 32 else 32   # rows per pass (solver.hpp: SDPB_SYRK2_RBG)
+        k_name = (f"k_syrk_fx2<{fx},{rbg},toom4> (+k_syrk4_finish)" if 32 * fx - 17 == fb else
+                  f"k_syrk_fx2<{fx},{rbg}> (+k_syrk_reduce)" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}> (+k_syrk_reduce)")
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_k_syrk_fx.json")
         if os.path.exists(pmc) and args.workload == "C4" and args.scale == 1.0 and world == 1:

@@ -1468,7 +1468,7 @@ template <int FX> constexpr bool fx_two_level()
   return FX % 4 == 0 && FX <= 32;
 #endif
 }
-// TOOM-4 (fx_toom4<FX>(): FX = 16 and 24, i.e. --precision 512 and 768):
+// TOOM-4 (fx_toom4<FX>(): FX = 16, 24, 32, i.e. --precision 512, 768 and 1024):
 // a' = a0 + a1 b + a2 b^2 + a3 b^3 with pieces of w = 32 M2 - 4 bits (b = 2^w, M2 = FX/4) is
 // evaluated at the seven points 0, 1, -1, 2, -2, 1/2, inf; the product polynomial of a row pair has
 // seven coefficients, so SEVEN products of M2 x M2 limbs per row pair (7/16 of the plain product)
@@ -1482,12 +1482,15 @@ template <int FX> constexpr bool fx_two_level()
 // fraction bits at --precision 512, where two Karatsuba levels keep 505 and the reference 512).
 // Image: seven M2-limb pieces per element, piece-major like the two-level image, group g =
 //   0: a0   1: p(1)   2: p(-1) + K1   3: p(2)   4: p(-2) + K2   5: 8 p(1/2)   6: a3.
+#ifndef SDPB_TOOM4_MAX_FX
+#define SDPB_TOOM4_MAX_FX 32
+#endif
 template <int FX> constexpr bool fx_toom4()
 {
 #if defined(SDPB_SYRK_ONE_LEVEL) || defined(SDPB_SYRK_NO_TOOM4)
   return false;
 #else
-  return FX % 4 == 0 && FX >= 16 && FX <= 24; // 512 and 768 bits: below, 17 bits are too large a share of the image
+  return FX % 4 == 0 && FX >= 16 && FX <= SDPB_TOOM4_MAX_FX; // 512 bits and up: below, 17 bits are too large a share of the image
 #endif
 }
 template <int FX> constexpr int fx_planes() { return fx_toom4<FX>() ? 7 * (FX / 4) : fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2); }

@@ -39,7 +39,7 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     o = Oracle(sdp, precision)
     fb = s.fx_frac_bits           # 32 FX - 17 (Toom-4: FX = 16, 24), - 7 (two Karatsuba levels: other FX % 4 == 0), else - 3
     fx = s.limbs - 2
-    assert fb == 32 * fx - (17 if fx in (16, 24) else 7 if fx % 4 == 0 else 3)
+    assert fb == 32 * fx - (17 if fx in (16, 24, 32) else 7 if fx % 4 == 0 else 3)
     rng = random.Random(7)
     vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
     vals[5] = 0
@@ -49,7 +49,7 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     vals[14] = -1
     # exactly at / next to the split points of the image a' = v + 2^fb (Karatsuba: first and second level;
     # Toom-4: the piece boundaries at multiples of 8 fx - 4 bits)
-    for k, bit in enumerate((8 * fx - 4, 16 * fx - 8, 24 * fx - 12, 8 * fx - 5) if fx in (16, 24) else
+    for k, bit in enumerate((8 * fx - 4, 16 * fx - 8, 24 * fx - 12, 8 * fx - 5) if fx in (16, 24, 32) else
                             (16 * fx - 1, 16 * fx - 3, 8 * fx - 1, 24 * fx - 4)):
         vals[15 + 2 * k] = 2 ** bit - 2 ** fb if bit < fb else 2 ** (bit - 1)
         vals[16 + 2 * k] = 2 ** bit - 2 ** fb - 1 if bit < fb else -(2 ** (bit - 1))
