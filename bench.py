@@ -330,7 +330,7 @@ def main():
     timers1 = solver.timers()
     syncs1 = solver.host_syncs
     # proof that N ranks exchanged: what every rank owns and what it handed to the transport
-    mine = {k[5:]: timers1[k] - (timers0.get(k, 0) if k.endswith(("_calls", "_bytes")) else 0) for k in timers1 if k.startswith("comm.")}
+    mine = {k[5:]: (timers1[k] - timers0.get(k, 0)) if k.endswith(("_calls", "_bytes")) else timers1[k] for k in timers1 if k.startswith("comm.")}
     mine["transport"] = solver.comm_name
     per_rank = [mine]
     if world > 1:
@@ -402,7 +402,10 @@ def main():
                                   "allreduce_calls_per_step": [r["allreduce_calls"] / args.steps for r in per_rank],
                                   "allreduce_MB_per_step": [round(r["allreduce_bytes"] / args.steps / 1e6, 3) for r in per_rank],
                                   "allgather_calls_per_step": [r["allgather_calls"] / args.steps for r in per_rank],
-                                  "allgather_MB_per_step": [round(r["allgather_bytes"] / args.steps / 1e6, 3) for r in per_rank]},
+                                  "allgather_MB_per_step": [round(r["allgather_bytes"] / args.steps / 1e6, 3) for r in per_rank],
+                                  "cholesky_Q": per_rank[0]["cholesky_Q"],
+                                  "broadcast_calls_per_step": [r["broadcast_calls"] / args.steps for r in per_rank],
+                                  "broadcast_MB_per_step": [round(r["broadcast_bytes"] / args.steps / 1e6, 3) for r in per_rank]},
             "roofline": {"bound": "hbm", "kernel": k_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,

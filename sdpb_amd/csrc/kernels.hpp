@@ -472,9 +472,10 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch
 // with A21 = rows below panel p, columns of panel p.   grid = (lower tiles, batch)
 // lower tiles [tile0, tile0 + gridDim.x) of the trailing matrix; the two 16 x KC operand
 // chunks of a tile are staged in limb-major LDS
+template <int NL>
+__device__ void chol_syrk_tile(const Batch &A, const MatDesc &d, int k0, int nb, int b0, int M, int ti, int tj, int cmin = 0, int cmax = 1 << 30);
 template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p, int tile0, unsigned long long *cyc)
 {
-  constexpr int KC = TRSM_KC, SN = 16 * KC;
   const int q = blockIdx.y;
   WgClock clk(cyc, q);
   const MatDesc d = A.d[q];
@@ -491,9 +492,49 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
   while((ti + 1) * (ti + 2) / 2 <= tile)
     ++ti;
   const int tj = tile - ti * (ti + 1) / 2;
+  chol_syrk_tile<NL>(A, d, k0, nb, b0, M, ti, tj);
+}
+// The same update restricted to the column panels q = q0, q0 + qstride, ... (count of them) of
+// the single matrix A.d[0]: the 1-D block-cyclic Cholesky(Q) over ranks updates only the panels a
+// rank owns.  grid = (row tiles of the trailing matrix, 2 tile columns per owned panel).
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_cols(Batch A, int p, int q0, int qstride, int count)
+{
+  static_assert(PB % 16 == 0 || PB < 16, "a panel is a whole number of 16-column tiles (or a single one)");
+  constexpr int TPP = PB >= 16 ? PB / 16 : 1; // tile columns per panel
+  const MatDesc d = A.d[0];
+  const int k0 = PB * p;
+  const int nb = d.rows - k0 < PB ? d.rows - k0 : PB;
+  const int b0 = k0 + nb, M = d.rows - b0;
+  const int which = (int)blockIdx.y / TPP, sub = (int)blockIdx.y % TPP;
+  if(M <= 0 || which >= count)
+    return;
+  const int q = q0 + which * qstride;            // owned panel, q > p
+  const int col0 = PB * q - b0;                   // first column of the panel inside the trailing matrix
+  if(col0 < 0 || col0 >= M)
+    return;
+  if constexpr(PB >= 16)
+    {
+      const int tj = col0 / 16 + sub, ti = (int)blockIdx.x;
+      if(tj * 16 >= M || ti < tj || ti * 16 >= M)
+        return;
+      chol_syrk_tile<NL>(A, d, k0, nb, b0, M, ti, tj);
+    }
+  else
+    {
+      // panels narrower than a tile (test builds with SDPB_PB = 4): the tile column that holds the panel;
+      // entries of neighbouring panels inside the tile are skipped by the column mask below
+      const int tj = col0 / 16, ti = (int)blockIdx.x;
+      if(ti < tj || ti * 16 >= M)
+        return;
+      chol_syrk_tile<NL>(A, d, k0, nb, b0, M, ti, tj, col0, col0 + PB);
+    }
+}
+template <int NL> __device__ void chol_syrk_tile(const Batch &A, const MatDesc &d, int k0, int nb, int b0, int M, int ti, int tj, int cmin, int cmax)
+{
+  constexpr int KC = TRSM_KC, SN = 16 * KC;
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
   const int i = ti * 16 + li, j = tj * 16 + lj;
-  const bool ok = i < M && j <= i;
+  const bool ok = i < M && j <= i && j >= cmin && j < cmax;
   __shared__ uint32_t sa[(NL + 2) * SN], sb[(NL + 2) * SN];
   Acc<NL> acc = mw::acc_zero<NL>();
   if(ok)
@@ -517,6 +558,59 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
     }
   if(ok)
     mat_st<NL>(A, d, b0 + i, b0 + j, mw::acc_result(acc));
+}
+
+// Panel message of the distributed Cholesky(Q) (1-D block-cyclic over ranks, one broadcast per
+// panel): the finished column panel p of the factor (rows k0 .. n-1, nb columns), the inverted diagonal
+// block Li_pp (nb x nb) and 1/L_ii (nb), limb-major with stride cnt = (n - k0) nb + nb nb + nb, then one
+// word: the owner's failure flag.  Unpacking also zeroes the panel's rows above the diagonal block
+// (the factor is lower triangular) and raises the local flag.
+template <int NL>
+__global__ void __launch_bounds__(WG) k_qpanel_pack(Batch A, Batch Li, Batch invd, int p, const int *fail, uint32_t *msg)
+{
+  const MatDesc d = A.d[0], di = Li.d[0], dv = invd.d[0];
+  const int k0 = PB * p, n = d.rows, nb = n - k0 < PB ? n - k0 : PB, rows = n - k0;
+  const size_t cnt = (size_t)rows * nb + (size_t)nb * nb + nb;
+  const size_t e = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(e == 0)
+    msg[cnt * (NL + 1)] = (uint32_t)fail[0];
+  if(e >= cnt)
+    return;
+  Mw<NL> v;
+  if(e < (size_t)rows * nb)
+    v = mat_ld<NL>(A, d, k0 + (int)(e % rows), k0 + (int)(e / rows));
+  else if(e < (size_t)rows * nb + (size_t)nb * nb)
+    {
+      const size_t f = e - (size_t)rows * nb;
+      v = mat_ld<NL>(Li, di, k0 + (int)(f % nb), k0 + (int)(f / nb));
+    }
+  else
+    v = mat_ld<NL>(invd, dv, k0 + (int)(e - (size_t)rows * nb - (size_t)nb * nb), 0);
+  mw::store<NL>(mw::Ptr{msg, cnt}, e, v);
+}
+template <int NL>
+__global__ void __launch_bounds__(WG) k_qpanel_unpack(Batch A, Batch Li, Batch invd, int p, int *fail, const uint32_t *msg)
+{
+  const MatDesc d = A.d[0], di = Li.d[0], dv = invd.d[0];
+  const int k0 = PB * p, n = d.rows, nb = n - k0 < PB ? n - k0 : PB, rows = n - k0;
+  const size_t cnt = (size_t)rows * nb + (size_t)nb * nb + nb;
+  const size_t e = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(e == 0 && msg[cnt * (NL + 1)])
+    atomicMax(fail, (int)msg[cnt * (NL + 1)]);
+  if(e < (size_t)k0 * nb) // rows above the diagonal block
+    mat_st<NL>(A, d, (int)(e % k0), k0 + (int)(e / k0), mw::zero<NL>());
+  if(e >= cnt)
+    return;
+  const Mw<NL> v = mw::load<NL>(mw::CPtr{msg, cnt}, e);
+  if(e < (size_t)rows * nb)
+    mat_st<NL>(A, d, k0 + (int)(e % rows), k0 + (int)(e / rows), v);
+  else if(e < (size_t)rows * nb + (size_t)nb * nb)
+    {
+      const size_t f = e - (size_t)rows * nb;
+      mat_st<NL>(Li, di, k0 + (int)(f % nb), k0 + (int)(f / nb), v);
+    }
+  else
+    mat_st<NL>(invd, dv, k0 + (int)(e - (size_t)rows * nb - (size_t)nb * nb), 0, v);
 }
 
 // The two strip steps of the look-ahead Cholesky(Q) sit between consecutive diagonal blocks on the

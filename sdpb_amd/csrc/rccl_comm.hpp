@@ -46,6 +46,11 @@ struct RcclComm : Comm
   {
     check(ncclAllReduce(buf, buf, count, ncclUint64, ncclSum, comm, st), "ncclAllReduce");
   }
+  bool broadcast(void *buf, size_t bytes, int root, hipStream_t st) override
+  {
+    check(ncclBroadcast(buf, buf, bytes, ncclUint8, root, comm, st), "ncclBroadcast");
+    return true;
+  }
   const char *name() const override { return "rccl"; }
   int ranks() const override
   {

@@ -53,6 +53,9 @@ struct Comm
   virtual void allreduce_sum_u64(void *dev_buf, size_t count, hipStream_t st) = 0;
   virtual const char *name() const = 0;
   virtual int ranks() const { return -1; } // size of the communicator as the transport reports it (-1: opaque callbacks)
+  // in-place broadcast of `bytes` from rank `root`; false = not offered by this transport (the caller
+  // then emulates it with an all-gather)
+  virtual bool broadcast(void *, size_t, int, hipStream_t) { return false; }
 };
 struct CallbackComm : Comm
 {
@@ -302,6 +305,14 @@ template <int NL> class Solver : public SolverBase
   };
   static_assert(R_COUNT <= X_MAXSLOTS, "result block too large for XOps");
   static constexpr size_t RES_WORDS = (size_t)(NL + 1) * R_COUNT + X_EXTRA;
+  DevBuf<uint32_t> qpanel_msg_, qpanel_gather_; // panel message of the distributed Cholesky(Q) (+ all-gather emulation of its broadcast)
+  // Cholesky(Q) distributed over the ranks (1-D block-cyclic over column panels, one broadcast per panel:
+  // SURVEY.md §8e; the reference factors Q over all ranks too, initialize_schur_complement_solver.cxx:95-103)
+  // instead of replicated.  Default: from N = 1536 up, where the N^3/3 trailing updates outweigh the
+  // per-panel broadcasts (C5-class); SDPB_HIP_DIST_CHOLQ=0/1 overrides.
+  bool dist_cholq_ = false;
+  long xc_broadcast_calls_ = 0;
+  double xc_broadcast_bytes_ = 0;
   DevBuf<uint32_t> resbuf_, xgather_, zero_piece_; // zero_piece_: what k_syrk_fx2 stages for rows/columns outside the image
   std::vector<M> res_host_ = std::vector<M>(R_COUNT);
   uint32_t xw_host_[X_EXTRA] = {0xffffffffu, 0, 0, 0};
@@ -638,6 +649,11 @@ private:
       profile_ = std::atoi(e) != 0;
     if(const char *e = std::getenv("SDPB_HIP_OVERLAP_SYRK"))
       overlap_syrk_ = std::atoi(e) != 0;
+    dist_cholq_ = world_ > 1 && N_ >= 1536;
+    if(const char *e = std::getenv("SDPB_HIP_DIST_CHOLQ"))
+      dist_cholq_ = world_ > 1 && std::atoi(e) != 0;
+    if(dist_cholq_)
+      qpanel_msg_.alloc(((size_t)N_ * PB + (size_t)PB * PB + PB) * (NL + 1) + 2);
     part2_.alloc((size_t)std::max(Jl_, 1) * N_, NL);
   }
 
@@ -724,7 +740,8 @@ public:
        << ", \"iterations\": " << iteration_ << ", \"comm.world\": " << world_ << ", \"comm.ranks\": " << (comm_ ? comm_->ranks() : (world_ == 1 ? 1 : 0))
        << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
        << ", \"comm.allgather_bytes\": " << xc_allgather_bytes_ << ", \"comm.allreduce_calls\": " << xc_allreduce_calls_
-       << ", \"comm.allreduce_bytes\": " << xc_allreduce_bytes_;
+       << ", \"comm.allreduce_bytes\": " << xc_allreduce_bytes_ << ", \"comm.broadcast_calls\": " << xc_broadcast_calls_
+       << ", \"comm.broadcast_bytes\": " << xc_broadcast_bytes_ << ", \"comm.cholesky_Q\": " << (dist_cholq_ ? "\"distributed\"" : "\"replicated\"");
     ss << "}";
     return ss.str();
   }
@@ -1385,7 +1402,9 @@ private:
           q_pending_ = true;
         }
     }
-    if(!side)
+    if(dist_cholq_)
+      cholesky_Q_distributed();
+    else if(!side)
       cholesky_Q_async();
   }
   unsigned long long *block_clock(int stage)
@@ -1486,6 +1505,62 @@ private:
     xc_allreduce_bytes_ += (double)(T * ACCW * 8);
     comm().allreduce_sum_u64(acc64_.p, T * ACCW, stream_);
     launch(k_narrow_tri_carry<0>, grid, dim3(WG), stream_, (const unsigned long long *)acc64_.p, N_, (int)ACCW, acc_.p, acc_stride_);
+  }
+  // in-place broadcast on the main stream through whatever the exchange runs on
+  void xbroadcast(uint32_t *buf, size_t words, int root)
+  {
+    const size_t bytes = words * sizeof(uint32_t);
+    xc_broadcast_calls_ += 1;
+    xc_broadcast_bytes_ += (double)bytes;
+    if(comm().broadcast(buf, bytes, root, stream_))
+      return;
+    if(qpanel_gather_.n < words * world_)
+      {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        qpanel_gather_.alloc(words * world_);
+      }
+    comm().allgather(buf, qpanel_gather_.p, bytes, stream_);
+    if(root != rank_)
+      HIP_CHECK(hipMemcpyAsync(buf, qpanel_gather_.p + (size_t)root * words, bytes, hipMemcpyDeviceToDevice, stream_));
+  }
+  // Cholesky(Q) over all ranks: column panel p belongs to rank p % world.  Step p: the owner factors and
+  // inverts the diagonal block, solves the rows below it and broadcasts the finished panel (with the
+  // inverted block and its failure flag); every rank then applies the panel to the column panels IT owns.
+  // Each rank ends with the whole factor (it received every panel), so the Q solves stay as they are.
+  // The N^3/3 trailing updates divide by the number of ranks; the chain of diagonal blocks does not.
+  // Runs on the main stream: its collectives stay ordered with the others of the iteration.
+  void cholesky_Q_distributed()
+  {
+    int *qflags = flags_.p + 2 * std::max(Jl_, 1);
+    const Batch A = QB(), invd = vecQB(invdQ_), Li{LiQ_.ptr(), d_Q_.p, 1};
+    const int panels = cdiv(N_, PB);
+    for(int p = 0; p < panels; ++p)
+      {
+        const int owner = p % world_, k0 = PB * p, nb = std::min(PB, N_ - k0), rows = N_ - k0;
+        const size_t cnt = (size_t)rows * nb + (size_t)nb * nb + nb, words = cnt * (NL + 1) + 1;
+        if(owner == rank_)
+          {
+            launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), stream_, A, invd, Li, p, qflags, (unsigned long long *)nullptr);
+            const int below = N_ - PB * (p + 1), above = PB * p;
+            if(std::max(below, above) > 0)
+              launch(k_chol_panel_solve<NL>, dim3(cdiv(std::max(below, above), TR), 1), dim3(WG), stream_, A, Li, p, 0, (unsigned long long *)nullptr);
+            launch(k_qpanel_pack<NL>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, A, Li, invd, p, (const int *)qflags, qpanel_msg_.p);
+          }
+        xbroadcast(qpanel_msg_.p, words, owner);
+        if(owner != rank_)
+          launch(k_qpanel_unpack<NL>, dim3(cdiv(std::max(cnt, (size_t)k0 * nb), WG)), dim3(WG), stream_, A, Li, invd, p, qflags, (const uint32_t *)qpanel_msg_.p);
+        // owned panels q > p: q = rank (mod world)
+        int q0 = p + 1;
+        while(q0 % world_ != rank_)
+          ++q0;
+        if(q0 < panels)
+          {
+            const int count = (panels - 1 - q0) / world_ + 1, M = N_ - (k0 + nb);
+            constexpr int TPP = PB >= 16 ? PB / 16 : 1;
+            launch(k_chol_syrk_cols<NL>, dim3(cdiv(M, 16), count * TPP), dim3(WG), stream_, A, p, q0, world_, count);
+          }
+      }
+    launch(k_fail_tags_q<0>, dim3(1), dim3(64), stream_, (const int *)qflags, xwords() + XW_FAIL);
   }
   // El::Cholesky(UPPER,Q) (initialize_schur_complement_solver.cxx:95-103), stored here
   // as the lower factor L = U^T (blocked, see kernels.hpp).  The factorisation is a long

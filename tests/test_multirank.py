@@ -17,3 +17,16 @@ def test_sharded_iteration_matches_reference(name, n_iter, world):
     for got, want in zip(results[0][2], iters):
         bad, _ = parity.compare_iteration(got, want)
         assert not bad, (want["iteration"], bad)
+
+
+@pytest.mark.parametrize("name,n_iter,world", [("singlet_cT", 3, 2), ("dfibo", 3, 3)])
+def test_cholesky_Q_distributed_over_the_ranks(name, n_iter, world):
+    """The 1-D block-cyclic Cholesky(Q) (one broadcast per column panel, every rank updates the panels it
+    owns) on the emulation build with 4-column panels: N = 20 / 19 gives five panels dealt to 2 / 3 ranks.
+    Same trace as the reference, ranks bit-identical."""
+    sdp, _, _, _, iters = _load(name)
+    results = run_ranks(world, name, n_iter, timeout=900, gpu=False, env={"SDPB_HIP_DIST_CHOLQ": "1"}, emu_panel=4)
+    check_ranks(results, world, sdp.J, "distributed", -(-sdp.N // 4))
+    for got, want in zip(results[0][2], iters):
+        bad, _ = parity.compare_iteration(got, want)
+        assert not bad, (want["iteration"], bad)

@@ -42,9 +42,10 @@ def _load(case):
     return sdp, meta["precision"], meta["params"], None, iters
 
 
-def _worker(rank, world, port, case, n_iter, q, gpu=True):
+def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(env or {})
     sys.path.insert(0, libs.ROOT)
     import torch
     import torch.distributed as dist
@@ -59,7 +60,8 @@ def _worker(rank, world, port, case, n_iter, q, gpu=True):
         sdp, precision, params, src, _ = _load(case)
         # gpu=False: the CPU twin of this test (tests/test_multirank.py) on the emulation build
         s = SDPSolver(sdp, precision, params, device=0, rank=rank, world_size=world,
-                      lib_path=libs.product_lib() if gpu else libs.emu_lib(), upload_all_blocks=False, block_source=src)
+                      lib_path=libs.product_lib() if gpu else libs.emu_lib(panel=emu_panel), upload_all_blocks=False,
+                      block_source=src)
         s.set_collectives(*make_collectives(dev))
         owners = [s.block_owner(j) for j in range(sdp.J)]
         recs = []
@@ -75,12 +77,12 @@ def _worker(rank, world, port, case, n_iter, q, gpu=True):
         dist.destroy_process_group()
 
 
-def run_ranks(world, case, n_iter, timeout=900, gpu=True):
+def run_ranks(world, case, n_iter, timeout=900, gpu=True, env=None, emu_panel=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, n_iter, q, gpu)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, n_iter, q, gpu, env, emu_panel)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=timeout) for _ in procs)
@@ -90,7 +92,7 @@ def run_ranks(world, case, n_iter, timeout=900, gpu=True):
     return results
 
 
-def check_ranks(results, world, J):
+def check_ranks(results, world, J, cholesky_Q="replicated", panels=None):
     owners0 = results[0][1]
     for rank, owners, recs, comm, name in results:
         assert owners == owners0                       # the same plan on every rank
@@ -100,6 +102,9 @@ def check_ranks(results, world, J):
         # per iteration: one Q' all-reduce, three result-block all-gathers + three N-vector all-gathers
         assert comm["comm.allreduce_calls"] >= len(recs) and comm["comm.allgather_calls"] >= 6 * len(recs)
         assert recs == results[0][2], f"rank {rank} diverged from rank 0"   # lock-step, bit for bit
+        assert comm["comm.cholesky_Q"] == cholesky_Q
+        if cholesky_Q == "distributed":   # one broadcast per column panel of Q and iteration
+            assert comm["comm.broadcast_calls"] == panels * len(recs), (comm["comm.broadcast_calls"], panels, len(recs))
     assert sorted(set(owners0)) == list(range(world)) and len(owners0) == J  # a partition, nobody idle
 
 
@@ -113,6 +118,30 @@ def test_ranks_sharing_one_gpu_match_the_reference_trace(world):
     for got, want in zip(results[0][2], iters):
         bad, _ = parity.compare_iteration(got, want)
         assert not bad, (want["iteration"], bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case,n_iter", [(2, "C4x0.25", 3), (3, "dfibo", 3)])
+def test_cholesky_Q_distributed_over_the_ranks_on_the_device(world, case, n_iter):
+    """Cholesky(Q) factored over the ranks (1-D block-cyclic column panels, one broadcast per panel;
+    reference: initialize_schur_complement_solver.cxx:95-103 factors Q over COMM_WORLD) instead of
+    replicated: C4 x0.25 (N = 250, eight panels) against the live oracle, dfibo (one panel) against
+    the golden trace; ranks bit-identical."""
+    sdp, precision, params, src, iters = _load(case)
+    results = run_ranks(world, case, n_iter, env={"SDPB_HIP_DIST_CHOLQ": "1"})
+    check_ranks(results, world, sdp.J, "distributed", -(-sdp.N // 32))
+    if iters is not None:
+        for got, want in zip(results[0][2], iters):
+            bad, _ = parity.compare_iteration(got, want)
+            assert not bad, (want["iteration"], bad)
+        return
+    from oracle.oracle import Oracle
+    o = Oracle(sdp, precision, params, param_prec=0, block_source=src)
+    for it in range(n_iter):
+        assert not o.iterate()
+        bad, _ = parity.compare_iteration(results[0][2][it], o.scalars(), tol_bits=precision // 2)
+        assert not bad, (it + 1, bad)
+    o.close()
 
 
 @pytest.mark.gpu
