@@ -1562,7 +1562,7 @@ template <int FX> constexpr bool fx_two_level()
   return FX % 4 == 0 && FX <= 32;
 #endif
 }
-// TOOM-4 (fx_toom4<FX>(): FX = 16, 24, 32, i.e. --precision 512, 768 and 1024):
+// TOOM-4 (fx_toom4<FX>(): FX = 16, 24, 32, 40, 48, i.e. --precision 512, 768, 1024, 1280, 1536):
 // a' = a0 + a1 b + a2 b^2 + a3 b^3 with pieces of w = 32 M2 - 4 bits (b = 2^w, M2 = FX/4) is
 // evaluated at the seven points 0, 1, -1, 2, -2, 1/2, inf; the product polynomial of a row pair has
 // seven coefficients, so SEVEN products of M2 x M2 limbs per row pair (7/16 of the plain product)
@@ -1577,7 +1577,7 @@ template <int FX> constexpr bool fx_two_level()
 // Image: seven M2-limb pieces per element, piece-major like the two-level image, group g =
 //   0: a0   1: p(1)   2: p(-1) + K1   3: p(2)   4: p(-2) + K2   5: 8 p(1/2)   6: a3.
 #ifndef SDPB_TOOM4_MAX_FX
-#define SDPB_TOOM4_MAX_FX 32
+#define SDPB_TOOM4_MAX_FX 48
 #endif
 template <int FX> constexpr bool fx_toom4()
 {
@@ -2851,7 +2851,9 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   // the register file, else (1024-bit operands: 9 x 18 limbs) the three of one first-level operand
   // at a time — three sweeps, the same passes in another order, each closed by its second-level
   // recombination into x[sweep]
-  constexpr int NG = TOOM ? 7 : FX >= 32 ? 3 : 9, SWEEPS = TOOM ? 1 : 9 / NG;
+  // (Toom-4: all seven up to 1024 bits — 226 VGPRs at FX = 32 — and four + three in two sweeps above)
+  constexpr int NGRP = TOOM ? 7 : 9;
+  constexpr int NG = TOOM ? (FX > 32 ? 4 : 7) : FX >= 32 ? 3 : 9, SWEEPS = (NGRP + NG - 1) / NG;
   uint32_t g2[NG][A2];
   uint32_t x[TOOM ? 1 : 3][TOOM ? 1 : A];
   // Staging of the NEXT pass.  16-byte pieces (M2 = 4) go HBM/L2 -> LDS directly
@@ -2939,6 +2941,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
       g2[g][k] = 0;
   if(sweep > 0)
     __syncthreads(); // every wavefront has left the last pass of the previous sweep
+  const int ngs = NGRP - sweep * NG < NG ? NGRP - sweep * NG : NG; // products of this sweep (compile time once unrolled)
   fetch(sweep * NG, row_begin, 0);
   store(0);
   __syncthreads();
@@ -2948,7 +2951,9 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 #pragma unroll
       for(int g = 0; g < NG; ++g)
         {
-          fetch(sweep * NG + (g < NG - 1 ? g + 1 : 0), g < NG - 1 ? r0 : r0 + RBG, buf ^ 1);
+          if(g >= ngs)
+            continue;
+          fetch(sweep * NG + (g < ngs - 1 ? g + 1 : 0), g < ngs - 1 ? r0 : r0 + RBG, buf ^ 1);
           uint64_t c[2 * M2 - 1];
           uint32_t h[2 * M2 - 1];
 #pragma unroll
@@ -2993,22 +2998,26 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
           buf ^= 1;
         }
     }
-  if constexpr(SWEEPS == 3)
-    second_level(sweep, 0);
-  }
   if constexpr(TOOM)
     {
       if(i < N && j <= i)
         {
           const size_t o = (size_t)i + (size_t)j * N;
 #pragma unroll
-          for(int g = 0; g < 7; ++g)
+          for(int g = 0; g < NG; ++g)
+            if(g < ngs)
+              {
 #pragma unroll
-            for(int k = 0; k < A2; ++k)
-              acc[(size_t)(g * A2 + k) * acc_stride + o] = g2[g][k];
+                for(int k = 0; k < A2; ++k)
+                  acc[(size_t)((sweep * NG + g) * A2 + k) * acc_stride + o] = g2[g][k];
+              }
         }
-      return;
     }
+  else if constexpr(SWEEPS == 3)
+    second_level(sweep, 0);
+  }
+  if constexpr(TOOM)
+    return;
   else
   {
   if constexpr(SWEEPS == 1)

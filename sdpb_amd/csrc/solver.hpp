@@ -2457,4 +2457,6 @@ __attribute__((weak)) SolverBase *make_solver_18(int, const std::vector<int> &, 
 __attribute__((weak)) SolverBase *make_solver_24(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
 __attribute__((weak)) SolverBase *make_solver_26(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
 __attribute__((weak)) SolverBase *make_solver_34(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_42(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_50(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
 } // namespace sdpb

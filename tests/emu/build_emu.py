@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sdpb_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
-# only the mantissa widths the CPU tests use (the factories are weak symbols): 128, 512, 664, 768, 1024 bits
-LIMBS = (6, 18, 24, 26, 34)
+# only the mantissa widths the CPU tests use (the factories are weak symbols): 128, 512, 664, 768, 1024, 1280 bits
+LIMBS = (6, 18, 24, 26, 34, 42)
 CXX = os.environ.get("CXX", "g++")
 FLAGS = ["-O1", "-std=c++17", "-fPIC", "-fopenmp", "-x", "c++", "-I" + os.path.join(HERE, "include"),
          "-Wno-unknown-pragmas", "-Wno-attributes", "-DSDPB_NO_RCCL"]
@@ -66,13 +66,17 @@ def build(force=False, panel=None):
                                                                  os.path.join(HERE, "hip_emu.cpp"),
                                                                  os.path.join(ROOT, "include", "sdpb_hip.h")]
     digest = _digest(deps)
+    sys.path.insert(0, ROOT)
+    from sdpb_amd.build import EXTRA_FLAGS as product_flags
     jobs, objs, todo = [], [], []
     for nl in (LIMBS if panel is None else (26,)):
         obj = os.path.join(OUT, f"solver_{nl}.o")
         objs.append(obj)
         if force or _stale(obj, digest):
             todo.append(obj)
-            jobs.append([CXX, *FLAGS, *extra, f"-DSDPB_NL={nl}", "-c", os.path.join(CSRC, "solver_nl.hip"), "-o", obj])
+            # same per-width flags as the product build (16-column panels above 1024 bits) unless a panel width is forced
+            per_nl = [] if panel is not None else product_flags.get(nl, [])
+            jobs.append([CXX, *FLAGS, *extra, *per_nl, f"-DSDPB_NL={nl}", "-c", os.path.join(CSRC, "solver_nl.hip"), "-o", obj])
     for src, name in ((os.path.join(CSRC, "capi.hip"), "capi.o"), (os.path.join(HERE, "hip_emu.cpp"), "hip_emu.o")):
         obj = os.path.join(OUT, name)
         objs.append(obj)

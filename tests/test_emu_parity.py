@@ -28,7 +28,8 @@ def test_emulated_library_matches_reference_golden(name, limit):
 
 @pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (128, 70, 21, "3"), (512, 45, 18, None),
                                                         (512, 100, 18, "3"), (768, 33, 17, None), (664, 20, 17, None),
-                                                        (1024, 40, 18, None), (1024, 40, 18, "2")])
+                                                        (1024, 40, 18, None), (1024, 40, 18, "2"), (1280, 36, 17, None),
+                                                        (1280, 70, 17, "2")])
 def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     import random
     if splits:
@@ -39,7 +40,7 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     o = Oracle(sdp, precision)
     fb = s.fx_frac_bits           # 32 FX - 17 (Toom-4: FX = 16, 24), - 7 (two Karatsuba levels: other FX % 4 == 0), else - 3
     fx = s.limbs - 2
-    assert fb == 32 * fx - (17 if fx in (16, 24, 32) else 7 if fx % 4 == 0 else 3)
+    assert fb == 32 * fx - (17 if fx in (16, 24, 32, 40, 48) else 7 if fx % 4 == 0 else 3)
     rng = random.Random(7)
     vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
     vals[5] = 0
@@ -49,7 +50,7 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     vals[14] = -1
     # exactly at / next to the split points of the image a' = v + 2^fb (Karatsuba: first and second level;
     # Toom-4: the piece boundaries at multiples of 8 fx - 4 bits)
-    for k, bit in enumerate((8 * fx - 4, 16 * fx - 8, 24 * fx - 12, 8 * fx - 5) if fx in (16, 24, 32) else
+    for k, bit in enumerate((8 * fx - 4, 16 * fx - 8, 24 * fx - 12, 8 * fx - 5) if fx in (16, 24, 32, 40, 48) else
                             (16 * fx - 1, 16 * fx - 3, 8 * fx - 1, 24 * fx - 4)):
         vals[15 + 2 * k] = 2 ** bit - 2 ** fb if bit < fb else 2 ** (bit - 1)
         vals[16 + 2 * k] = 2 ** bit - 2 ** fb - 1 if bit < fb else -(2 ** (bit - 1))
@@ -63,7 +64,7 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
                 assert got[i + j * cols] == 0
 
 
-@pytest.mark.parametrize("precision", [128, 512, 664, 768, 1024])
+@pytest.mark.parametrize("precision", [128, 512, 664, 768, 1024, 1280])
 def test_emulated_syrk_Q_stage_and_saturated_columns(precision):
     """compute_Q.cxx:94-132 as an operator (calculate_matrix_square.test.cxx recipe) incl. columns with
     a single negative entry: the normalised value saturates the fixed-point image, whose clamp must
@@ -123,6 +124,23 @@ def test_emulated_library_beyond_one_panel_of_Q():
     for it in range(3):
         assert not s.iterate() and not o.iterate()
         bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=256)
+        assert not bad, (it + 1, bad)
+    s.close()
+    o.close()
+
+
+def test_emulated_iterations_above_1024_bits():
+    """--precision 1280 (42 limbs, 16-column panels, Toom-4 syrk in two sweeps): the reference accepts any
+    precision (Solver_Parameters.cxx:20-26); whole iterations of the m = 2 golden SDP against the oracle at
+    the same precision, tolerance 2^-(p/2)."""
+    from oracle.oracle import Oracle
+    sdp, meta, _, _ = parity.load_case("1d-constraints")
+    o = Oracle(sdp, 1280, meta["params"], param_prec=64)
+    s = SDPSolver(sdp, 1280, parity.reference_params(meta["params"], o), lib_path=libs.emu_lib())
+    assert s.limbs == 42
+    for it in range(4):
+        assert not s.iterate() and not o.iterate()
+        bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=640)
         assert not bad, (it + 1, bad)
     s.close()
     o.close()
