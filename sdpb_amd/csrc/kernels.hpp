@@ -76,30 +76,78 @@ template <int NL, int OP> MW_HD Mw<NL> red_combine(const Mw<NL> &a, const Mw<NL>
     return mw::max(a, b);
   return mw::min(a, b);
 }
-// Workgroup tree reduction through LDS; result valid in thread 0.
+// Workgroup reduction; result valid in thread 0.  Inside a wavefront the 64 partial results meet by
+// wavefront shuffles (__shfl_down: lane t takes lane t + s, s = 32 ... 1, one word of the multi-word
+// number at a time — no LDS traffic, no barrier); the four wavefront results then meet through LDS in a
+// fixed order.  The CPU emulation build walks the same tree through memory, so both give the same bits.
 template <int NL, int OP> __device__ Mw<NL> wg_reduce(Mw<NL> v, bool has)
 {
-  __shared__ Mw<NL> sm[WG];
-  __shared__ int sh[WG];
-  const int t = threadIdx.x;
-  sm[t] = v;
-  sh[t] = has ? 1 : 0;
-  __syncthreads();
-  for(int s = WG / 2; s > 0; s >>= 1)
+  constexpr int WAVES = WG / 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int h = has ? 1 : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for(int s = 32; s > 0; s >>= 1)
     {
-      if(t < s && sh[t + s])
+      Mw<NL> o;
+#pragma unroll
+      for(int l = 0; l < NL; ++l)
+        o.m[l] = (uint32_t)__shfl_down((int)v.m[l], s, 64);
+      o.e = __shfl_down(v.e, s, 64);
+      o.neg = (uint32_t)__shfl_down((int)v.neg, s, 64);
+      const int oh = __shfl_down(h, s, 64);
+      if(lane + s < 64 && oh)
         {
-          if(sh[t])
-            sm[t] = red_combine<NL, OP>(sm[t], sm[t + s]);
-          else
-            {
-              sm[t] = sm[t + s];
-              sh[t] = 1;
-            }
+          v = h ? red_combine<NL, OP>(v, o) : o;
+          h = 1;
         }
-      __syncthreads();
     }
-  Mw<NL> r = sm[0];
+#else
+  {
+    __shared__ Mw<NL> sm[WG];
+    __shared__ int sh[WG];
+    sm[t] = v;
+    sh[t] = h;
+    __syncthreads();
+    for(int s = 32; s > 0; s >>= 1)
+      {
+        // every lane reads its partner before any lane of the step writes (the shuffle's semantics)
+        const bool take = lane + s < 64 && sh[lane + s < 64 ? t + s : t];
+        const Mw<NL> o = sm[lane + s < 64 ? t + s : t];
+        __syncthreads();
+        if(take)
+          {
+            sm[t] = sh[t] ? red_combine<NL, OP>(sm[t], o) : o;
+            sh[t] = 1;
+          }
+        __syncthreads();
+      }
+    v = sm[t];
+    h = sh[t];
+    __syncthreads();
+  }
+#endif
+  __shared__ Mw<NL> sw[WAVES];
+  __shared__ int shw[WAVES];
+  if(lane == 0)
+    {
+      sw[wave] = v;
+      shw[wave] = h;
+    }
+  __syncthreads();
+  Mw<NL> r = mw::zero<NL>();
+  if(t == 0)
+    {
+      // pairs of wavefronts, then the pairs: ((w0 . w1) . (w2 . w3))
+      for(int step = 1; step < WAVES; step <<= 1)
+        for(int w = 0; w + step < WAVES; w += 2 * step)
+          if(shw[w + step])
+            {
+              sw[w] = shw[w] ? red_combine<NL, OP>(sw[w], sw[w + step]) : sw[w + step];
+              shw[w] = 1;
+            }
+      r = sw[0];
+    }
   __syncthreads();
   return r;
 }
@@ -1046,6 +1094,13 @@ __global__ void __launch_bounds__(WG) k_qsolve_panel(Batch Q, Batch Linv, mw::Pt
 // (a lone wavefront issues a multiply-add pair every 18 cycles, half of what its SIMD can take, and an
 // aligned add costs it ~1 us: fewer, fatter lanes do not pay).  The substitution is a chain of 2 N/PB
 // such launches per right-hand side, replicated on every GPU, so its length is what matters.
+// Round 3, measured and rejected (profiles/r03f_qsolve_big_steps.txt): the same substitution in steps of
+// 128 columns with explicitly inverted 128 x 128 diagonal blocks (assembled from the 32 x 32 inverses by block
+// substitution).  16 instead of 64 launches per right-hand side, but a launch then carries 12 products per
+// lane of a 1024-lane workgroup, and with four wavefronts per SIMD a dependent multi-word multiply-add takes
+// 3.8 us (the SIMD's 2280 cycles per wavefront-term are a throughput figure): 123 / 91 us per launch
+// forward / backward, 3.4 instead of 4.8 ms per iteration for the substitutions, plus 1.2 ms for the block
+// inverses on the Cholesky(Q) chain — no net gain at one rank or at eight.
 constexpr int QS2_T = PB * PB <= 1024 ? PB * PB : 1024;
 constexpr int QS2_G = PB < 4 ? PB : 4; // lanes per row in the first level of the sum
 #ifdef SDPB_QS_TRACE

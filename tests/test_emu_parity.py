@@ -144,3 +144,20 @@ def test_emulated_iterations_above_1024_bits():
         assert not bad, (it + 1, bad)
     s.close()
     o.close()
+
+
+def test_emulated_five_panels_of_Q():
+    """N = 150: five 32-column panels of Cholesky(Q) (the last one ragged, 22 columns) and of both sweeps of
+    the Q substitution, against the oracle."""
+    from oracle.oracle import Oracle
+    from sdpb_amd.synthetic import make_sdp
+    sdp = make_sdp([1] * 6, [30] * 6, 150, 512, seed=13)
+    s = SDPSolver(sdp, 512, parity.DEFAULT_PARAMS, lib_path=libs.emu_lib())
+    o = Oracle(sdp, 512, parity.DEFAULT_PARAMS, param_prec=0)
+    for it in range(2):
+        assert not s.iterate() and not o.iterate()
+        bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=256)
+        assert not bad, (it + 1, bad)
+        assert parity.maxrel(s.array("dy"), o.array("dy")) <= -256
+    s.close()
+    o.close()
