@@ -258,6 +258,8 @@ def main():
     precision = cfg["precision"]
     sdp, source = synthetic.make_lazy(cfg["dims"], cfg["num_points"], cfg["N"], precision, cfg["seed"])
     t_setup = time.time()
+    if sim:   # the faked exchange cannot supply the panels other ranks would factor
+        os.environ["SDPB_HIP_DIST_CHOLQ"] = "0"
     solver = SDPSolver(sdp, precision, device=local_rank, rank=rank, world_size=sim or world, upload_all_blocks=False,
                        block_source=source, lib_path=args.lib)
     if world > 1:
