@@ -461,9 +461,6 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
 constexpr int TR = WG / PB;
 // 4 columns per chunk: 31 KB of LDS per workgroup = 5 workgroups per CU; measured on C4 (P = L^{-1}B stage):
 // KC 16: 41.5 ms, 8: 37.5 ms, 4: 35.6 ms, 2: 35.9 ms
-#ifndef SDPB_TRSM_PREFETCH
-#define SDPB_TRSM_PREFETCH 0
-#endif
 #ifndef SDPB_TRSM_KC
 #define SDPB_TRSM_KC 4
 #endif
@@ -760,39 +757,6 @@ MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const 
   Acc<NL> acc = mw::acc_zero<NL>();
   if(ok)
     mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
-#if SDPB_TRSM_PREFETCH
-  // one staged number per lane and chunk (SXN + SLN <= WG): the loads of chunk k + KC are issued before the
-  // products of chunk k, so that their latency runs beside the multiply-adds instead of in front of the barrier
-  static_assert(SXN + SLN <= WG, "one staged element per lane");
-  const int e = threadIdx.x;
-  auto fetch = [&](int k) __attribute__((always_inline)) {
-    if(e < SXN)
-      {
-        const int kk = e / ROWS, rr = e % ROWS;
-        return r0 + rr < dx.rows ? mat_ld<NL>(X, dx, r0 + rr, k + kk) : mw::zero<NL>();
-      }
-    const int f = e - SXN, kk = f / COLS, jj = f % COLS;
-    return (e < SXN + SLN && jj < nb) ? mat_ld<NL>(L, dl, k0 + jj, k + kk) : mw::zero<NL>();
-  };
-  Mw<NL> pre = k0 > 0 ? fetch(0) : mw::zero<NL>();
-  for(int k = 0; k < k0; k += KC) // k0 is a multiple of PB, PB of KC
-    {
-      if(e < SXN)
-        smem_st<NL, SXN>(sx, e, pre);
-      else if(e < SXN + SLN)
-        smem_st<NL, SLN>(sl, e - SXN, pre);
-      __syncthreads();
-      if(k + KC < k0)
-        pre = fetch(k + KC);
-      if(ok)
-        {
-#pragma unroll 1
-          for(int kk = 0; kk < KC; ++kk)
-            mw::acc_fms(acc, smem_ld<NL, SXN>(sx, kk * ROWS + rl), smem_ld<NL, SLN>(sl, kk * COLS + j));
-        }
-      __syncthreads();
-    }
-#else
   for(int k = 0; k < k0; k += KC) // k0 is a multiple of PB, PB of KC
     {
       for(int e = threadIdx.x; e < SXN + SLN; e += WG)
@@ -817,7 +781,6 @@ MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const 
         }
       __syncthreads();
     }
-#endif
   smem_st<NL, STN>(st, j * ROWS + rl, ok ? mw::acc_result(acc) : mw::zero<NL>());
   acc = mw::acc_zero<NL>();
   // X(r, k0+j) = sum_{j2 <= j} T(r, j2) Li(k0+j, k0+j2)
