@@ -13,10 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsdpb_hip.so")
-ALL_LIMBS = (6, 10, 16, 18, 24, 26, 34, 42)  # 128, 256, 400/448, 512, 640-704, 768, 1024, 1280 bits
-# (50 limbs = 1536 bits compile and pass on the CPU emulation build, but the first device kernel that needs the whole
-#  register file — 256 VGPRs + 255 AGPRs + scratch at one wave per SIMD — does not come back on gfx950; not shipped
-#  until that is understood: SDPB_LIMBS=...,50 builds it for experiments)
+ALL_LIMBS = (6, 10, 16, 18, 24, 26, 34, 42, 50)  # 128, 256, 400/448, 512, 640-704, 768, 1024, 1280, 1536 bits
 # SDPB_LIMBS=18 builds a subset (developer iterations); the default builds every width.
 LIMBS = tuple(int(x) for x in os.environ["SDPB_LIMBS"].split(",")) if os.environ.get("SDPB_LIMBS") else ALL_LIMBS
 # Above 1024 bits the 32-column panel images of the chain kernels (k_chol_inv_lds: factor + inverse of a

@@ -147,7 +147,7 @@ int sdpb_hip_create_with_costs(int precision_bits, int num_blocks, const int *di
           }
       if(!s)
         return fail(nullptr, 4, "sdpb_hip_create: no compiled mantissa width covers --precision " + std::to_string(precision_bits)
-                                   + ": this library is built for 128 ... 1280 bits (limb counts 6, 10, 16, 18, 24, 26, 34, 42; "
+                                   + ": this library is built for 128 ... 1536 bits (limb counts 6, 10, 16, 18, 24, 26, 34, 42, 50; "
                                      "sdpb_amd/build.py, ALL_LIMBS)");
       ctx->solver.reset(s);
       *out = ctx.release();

@@ -2117,19 +2117,16 @@ public:
     io.alloc(3, NL);
     upload<NL>(io, 0, std::vector<M>{mw::from_decimal<NL>(a), mw::from_decimal<NL>(b)});
     mw::Ptr p = io.ptr();
-    foreach(1, [=] __device__(size_t) {
-      const M x = mw::load<NL>(p, 0), y = mw::load<NL>(p, 1);
-      M r;
-      switch(code)
-        {
-        case 0: r = mw::add(x, y); break;
-        case 1: r = mw::sub(x, y); break;
-        case 2: r = mw::mul(x, y); break;
-        case 3: r = mw::div(x, y); break;
-        default: r = mw::sqrt(x); break;
-        }
-      mw::store<NL>(p, 2, r);
-    });
+    // one kernel per operation: with all five inlined behind a switch the kernel needs the whole register
+    // file at 50 limbs (256 VGPRs + 255 AGPRs + scratch) and does not return on gfx950
+    switch(code)
+      {
+      case 0: foreach(1, [=] __device__(size_t) { mw::store<NL>(p, 2, mw::add(mw::load<NL>(p, 0), mw::load<NL>(p, 1))); }); break;
+      case 1: foreach(1, [=] __device__(size_t) { mw::store<NL>(p, 2, mw::sub(mw::load<NL>(p, 0), mw::load<NL>(p, 1))); }); break;
+      case 2: foreach(1, [=] __device__(size_t) { mw::store<NL>(p, 2, mw::mul(mw::load<NL>(p, 0), mw::load<NL>(p, 1))); }); break;
+      case 3: foreach(1, [=] __device__(size_t) { mw::store<NL>(p, 2, mw::div(mw::load<NL>(p, 0), mw::load<NL>(p, 1))); }); break;
+      default: foreach(1, [=] __device__(size_t) { mw::store<NL>(p, 2, mw::sqrt(mw::load<NL>(p, 0))); }); break;
+      }
     HIP_CHECK(hipStreamSynchronize(stream_));
     return mw::to_decimal<NL>(download<NL>(io, 2, 1)[0]);
   }

@@ -16,7 +16,7 @@ def _solver(sdp, precision, params=None):
 
 
 # ---- arithmetic: device ops vs GMP mpf (oracle), tolerance 2 ulp of the device mantissa
-@pytest.mark.parametrize("precision", [128, 256, 512, 768, 1024, 1280])
+@pytest.mark.parametrize("precision", [128, 256, 512, 768, 1024, 1280, 1536])
 def test_device_arithmetic_matches_mpf(precision):
     from oracle.oracle import Oracle
     sdp, _, _, _ = parity.load_case("1d")
@@ -37,7 +37,7 @@ def test_device_arithmetic_matches_mpf(precision):
 
 
 # ---- the syrk_Q stage as an operator: calculate_matrix_square.test.cxx recipe + saturated columns
-@pytest.mark.parametrize("precision", [128, 256, 400, 512, 664, 768, 1024, 1280])
+@pytest.mark.parametrize("precision", [128, 256, 400, 512, 664, 768, 1024, 1280, 1536])
 def test_syrk_Q_stage_and_saturated_columns(precision):
     sdp, _, _, _ = parity.load_case("1d")
     s = _solver(sdp, precision)
@@ -52,7 +52,7 @@ def test_config_C1_at_its_stated_precision_128():
 
 
 # ---- above 1024 bits (the reference accepts any --precision, Solver_Parameters.cxx:20-26)
-@pytest.mark.parametrize("precision,limbs", [(1100, 42), (1280, 42)])
+@pytest.mark.parametrize("precision,limbs", [(1100, 42), (1280, 42), (1536, 50)])
 def test_iterations_above_1024_bits(precision, limbs):
     from oracle.oracle import Oracle
     sdp, meta, _, _ = parity.load_case("1d-constraints")
@@ -70,15 +70,15 @@ def test_iterations_above_1024_bits(precision, limbs):
 def test_precision_beyond_the_compiled_widths_is_a_clear_error():
     from sdpb_amd.solver import SDPBError
     sdp, _, _, _ = parity.load_case("1d")
-    with pytest.raises(SDPBError, match="built for 128 ... 1280 bits"):
-        _solver(sdp, 1400)
+    with pytest.raises(SDPBError, match="built for 128 ... 1536 bits"):
+        _solver(sdp, 1700)
 
 
 # ---- the dominant kernel: fixed-point syrk is bit exact (integers)
 @pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (512, 300, 50, None), (512, 9, 1, None),
                                                         (1024, 64, 33, None), (512, 300, 50, "4"), (256, 100, 40, "16"),
                                                         (768, 130, 40, "3"), (1024, 200, 33, "2"), (1280, 64, 33, None),
-                                                        (1280, 90, 20, "2")])
+                                                        (1536, 90, 20, "2")])
 def test_int_syrk_bit_exact(precision, rows, cols, splits, monkeypatch):
     from oracle.oracle import Oracle
     if splits:
