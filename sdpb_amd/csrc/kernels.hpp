@@ -76,6 +76,22 @@ template <int NL, int OP> MW_HD Mw<NL> red_combine(const Mw<NL> &a, const Mw<NL>
     return mw::max(a, b);
   return mw::min(a, b);
 }
+// the multi-word number lane `src` of this wavefront holds (every lane of the wavefront must call it)
+template <int NL> __device__ Mw<NL> wave_get(const Mw<NL> &v, int src)
+{
+  Mw<NL> o;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for(int l = 0; l < NL; ++l)
+    o.m[l] = (uint32_t)__shfl((int)v.m[l], src, 64);
+  o.e = __shfl(v.e, src, 64);
+  o.neg = (uint32_t)__shfl((int)v.neg, src, 64);
+#else
+  o = v; // the emulation build never calls it (its lanes are fibres, not a wavefront)
+  (void)src;
+#endif
+  return o;
+}
 // Workgroup reduction; result valid in thread 0.  Inside a wavefront the 64 partial results meet by
 // wavefront shuffles (__shfl_down: lane t takes lane t + s, s = 32 ... 1, one word of the multi-word
 // number at a time — no LDS traffic, no barrier); the four wavefront results then meet through LDS in a
@@ -1553,7 +1569,6 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
   const int p = blockIdx.x * 4 + sub;
   // the 64 partial sums of a row meet in a limb-major LDS image and are added exactly, eight at a time
   // by eight lanes and then by one (two barriers instead of a six-level tree of rounded adds)
-  __shared__ uint32_t sm[(NL + 2) * WG];
   Acc<NL> sum = mw::acc_zero<NL>();
   if(p < bl.P)
     {
@@ -1561,6 +1576,26 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
       for(int n = lane; n < N; n += 64)
         mw::acc_fma(sum, mat_ld<NL>(MT, dm, n, p), mw::load<NL>(v, n));
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // A row is one wavefront: its 64 partial sums meet by wavefront shuffles (no LDS image, no barrier), in
+  // the same two exact levels and the same order as the LDS path below (which the emulation build runs):
+  // lane l adds the partials of lanes l % 8, l % 8 + 8, ..., then the eight level-1 sums are added to out.
+  {
+    const Mw<NL> mine = mw::acc_result(sum);
+    Acc<NL> a = mw::acc_zero<NL>();
+    for(int g = 0; g < 8; ++g)
+      mw::acc_add(a, wave_get<NL>(mine, g * 8 + (lane & 7)));
+    const Mw<NL> s8 = mw::acc_result(a);
+    Acc<NL> t = mw::acc_zero<NL>();
+    if(p < bl.P) // uniform in the wavefront
+      mw::acc_add(t, mw::load<NL>(out, (size_t)bl.voff + p));
+    for(int g = 0; g < 8; ++g)
+      mw::acc_add(t, wave_get<NL>(s8, g), sign < 0 ? 1u : 0u);
+    if(lane == 0 && p < bl.P)
+      mw::store<NL>(out, (size_t)bl.voff + p, mw::acc_result(t));
+  }
+#else
+  __shared__ uint32_t sm[(NL + 2) * WG];
   smem_st<NL, WG>(sm, threadIdx.x, mw::acc_result(sum));
   __syncthreads();
   if(lane < 8)
@@ -1579,6 +1614,7 @@ __global__ void __launch_bounds__(WG) k_gemv_n(Batch MT, mw::CPtr v, mw::Ptr out
         mw::acc_add(a, smem_ld<NL, WG>(sm, sub * 64 + g), sign < 0 ? 1u : 0u);
       mw::store<NL>(out, (size_t)bl.voff + p, mw::acc_result(a));
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------

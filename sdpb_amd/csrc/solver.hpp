@@ -251,7 +251,10 @@ template <int NL> class Solver : public SolverBase
   unsigned long long Ptot_global_ = 0; // sum over all ranks
   size_t psd_elems_ = 0, psd_rows_local_ = 0;
   long total_psd_rows_ = 0; // global (step.cxx:143)
-  hipStream_t stream_ = nullptr;
+  // stream_main_ is the library's stream; stream_ is the stream launches currently go to — normally the
+  // same, for a scope one of the side streams (OnSideStream, the CU-masked stream beside Cholesky(Q)).  The
+  // named streams themselves never change after construction.
+  hipStream_t stream_main_ = nullptr, stream_ = nullptr;
 
   // ---- descriptors -----------------------------------------------------------
   DevBuf<BlockDesc> d_blk_;
@@ -394,7 +397,8 @@ public:
       HIP_CHECK(hipGetDeviceProperties(&prop, dev));
       num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    HIP_CHECK(hipStreamCreate(&stream_));
+    HIP_CHECK(hipStreamCreate(&stream_main_));
+    stream_ = stream_main_;
     {
       // The side stream carries latency-bound dependent chains (Cholesky(Q): 1000 pivots in a row)
       // next to throughput work on the main stream: at high priority its small launches are
@@ -409,7 +413,7 @@ public:
       if(const char *e = std::getenv("SDPB_HIP_SINGLE_STREAM"))
         single_stream_ = std::atoi(e) != 0;
       if(single_stream_)
-        stream_q_ = stream_q2_ = stream_;
+        stream_q_ = stream_q2_ = stream_main_;
       else
         {
           HIP_CHECK(hipStreamCreateWithPriority(&stream_q_, hipStreamNonBlocking, prio));
@@ -468,8 +472,8 @@ public:
       (void)hipEventDestroy(ev_syrk0_);
     if(ev_syrk1_)
       (void)hipEventDestroy(ev_syrk1_);
-    if(stream_)
-      (void)hipStreamDestroy(stream_);
+    if(stream_main_)
+      (void)hipStreamDestroy(stream_main_);
   }
   int limbs() const override { return NL; }
   int fx_frac_bits() const override { return sdpb::fx_frac_bits<FX>(); }
@@ -1038,12 +1042,13 @@ private:
     comm().allgather(a.base, xgather_.p, words * sizeof(uint32_t), stream_);
     launch(k_combine_vec<NL>, dim3(cdiv(count, WG)), dim3(WG), stream_, (const uint32_t *)xgather_.p, world_, (int)count, a.ptr());
   }
-  // streams are exchanged for a scope (exception safe)
+  // launches go to the side stream for a scope (exception safe; restores whatever was current)
   struct OnSideStream
   {
     Solver *s;
-    explicit OnSideStream(Solver *s_) : s(s_) { std::swap(s->stream_, s->stream_q_); }
-    ~OnSideStream() { std::swap(s->stream_, s->stream_q_); }
+    hipStream_t prev;
+    explicit OnSideStream(Solver *s_) : s(s_), prev(s_->stream_) { s->stream_ = s->stream_q_; }
+    ~OnSideStream() { s->stream_ = prev; }
   };
   void resolve_syrk_events()
   {
@@ -1580,7 +1585,7 @@ private:
       {
         HIP_CHECK(hipEventRecord(ev_beside_, stream_));
         HIP_CHECK(hipStreamWaitEvent(stream_beside_, ev_beside_, 0));
-        std::swap(stream_, stream_beside_);
+        stream_ = stream_beside_;
         beside_active_ = true;
       }
   }
@@ -1590,9 +1595,9 @@ private:
   {
     if(!beside_active_)
       return;
-    (void)hipEventRecord(ev_beside_, stream_);
-    std::swap(stream_, stream_beside_);
-    (void)hipStreamWaitEvent(stream_, ev_beside_, 0);
+    (void)hipEventRecord(ev_beside_, stream_beside_);
+    stream_ = stream_main_;
+    (void)hipStreamWaitEvent(stream_main_, ev_beside_, 0);
     beside_active_ = false;
   }
   // the main stream waits for the factor of Q (device-side); failures become tags
