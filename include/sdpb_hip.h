@@ -38,7 +38,9 @@ typedef struct sdpb_hip_ctx sdpb_hip_ctx;
  * K_j (block_info_<j>.json), N = length of b.  Blocks are assigned to ranks by a
  * deterministic cost model (analogue of compute_block_grid_mapping.hxx:58-183);
  * rank/world_size describe this process (one process per GPU).  device_id < 0 keeps
- * the current device. */
+ * the current device.  precision_bits is sdpb's --precision (Solver_Parameters.cxx:20-26): it is
+ * rounded up to the next compiled mantissa width (128 ... 1536 bits; code 4 with a message naming
+ * the range beyond that), as GMP rounds a precision up to whole limbs. */
 int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
                     int rank, int world_size, sdpb_hip_ctx **out);
 void sdpb_hip_destroy(sdpb_hip_ctx *ctx);
