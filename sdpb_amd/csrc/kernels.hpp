@@ -1667,6 +1667,12 @@ template <int FX> constexpr bool fx_two_level()
 // fraction bits at --precision 512, where two Karatsuba levels keep 505 and the reference 512).
 // Image: seven M2-limb pieces per element, piece-major like the two-level image, group g =
 //   0: a0   1: p(1)   2: p(-1) + K1   3: p(2)   4: p(-2) + K2   5: 8 p(1/2)   6: a3.
+// Limbs of the fixed-point image for an NL-limb mantissa: GMP's rounded precision 64 (l - 1) = 32 (NL - 2) bits
+// (compute_Q.cxx:107), rounded UP to a multiple of four limbs from 14 limbs on, so that every precision from
+// sdpb's default 400 bits upwards takes the Toom-4 kernel (400/448 bits: 16 instead of 14 limbs, 640-704 bits:
+// 24 instead of 22).  The image then holds more fraction bits than the reference's (495 against 448, 751 against
+// 704) at 7/16 of 16^2 = 112 instead of 3/4 of 14^2 = 147 limb products per row pair.
+template <int NL> constexpr int fx_limbs() { return (NL - 2 >= 14 && (NL - 2) % 4 != 0) ? ((NL - 2 + 3) / 4) * 4 : NL - 2; }
 #ifndef SDPB_TOOM4_MAX_FX
 #define SDPB_TOOM4_MAX_FX 48
 #endif

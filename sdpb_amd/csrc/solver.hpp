@@ -230,7 +230,8 @@ inline void split_numbers(const char *txt, std::vector<std::pair<const char *, c
 template <int NL> class Solver : public SolverBase
 {
   using M = Mw<NL>;
-  static constexpr int FX = NL - 2; // 32*FX = GMP's rounded precision 64*(l-1) (compute_Q.cxx:107)
+  static constexpr int FX = fx_limbs<NL>(); // 32 (NL - 2) = GMP's rounded precision 64 (l - 1) (compute_Q.cxx:107), or the next multiple of four limbs
+  static_assert(FX <= NL, "the image is cut from an NL-limb product");
   static constexpr int ACCW = 2 * FX + 2;
   static constexpr bool SYRK_TOOM4 = fx_toom4<FX>();         // seven (FX/4)^2 products per row pair (k_syrk_fx2<.., true> + k_syrk4_finish)
   static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>() || SYRK_TOOM4; // piece-major image: nine (two Karatsuba levels) or seven pieces

@@ -78,7 +78,8 @@ def test_precision_beyond_the_compiled_widths_is_a_clear_error():
 @pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (512, 300, 50, None), (512, 9, 1, None),
                                                         (1024, 64, 33, None), (512, 300, 50, "4"), (256, 100, 40, "16"),
                                                         (768, 130, 40, "3"), (1024, 200, 33, "2"), (1280, 64, 33, None),
-                                                        (1536, 90, 20, "2")])
+                                                        (1536, 90, 20, "2"), (400, 50, 20, None),
+                                                        (664, 64, 33, "2")])
 def test_int_syrk_bit_exact(precision, rows, cols, splits, monkeypatch):
     from oracle.oracle import Oracle
     if splits:
