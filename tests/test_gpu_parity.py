@@ -67,6 +67,21 @@ def test_iterations_above_1024_bits(precision, limbs):
     o.close()
 
 
+# ---- sdpb's DEFAULT --precision 400 (16 limbs; the fixed-point image padded from 14 to 16 limbs takes the Toom-4 kernel)
+def test_iterations_at_the_default_precision_400():
+    from oracle.oracle import Oracle
+    sdp, meta, _, _ = parity.load_case("singlet_cT")
+    o = Oracle(sdp, 400, meta["params"], param_prec=64)
+    s = _solver(sdp, 400, parity.reference_params(meta["params"], o))
+    assert s.limbs == 16 and s.fx_frac_bits == 495
+    for it in range(12):
+        assert not s.iterate() and not o.iterate()
+        bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=200)
+        assert not bad, (it + 1, bad)
+    s.close()
+    o.close()
+
+
 def test_precision_beyond_the_compiled_widths_is_a_clear_error():
     from sdpb_amd.solver import SDPBError
     sdp, _, _, _ = parity.load_case("1d")
