@@ -142,8 +142,10 @@ int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j);
 int sdpb_hip_limbs(sdpb_hip_ctx *ctx);
 /* Fraction bits FB of the fixed-point image of the normalised P' that the exact integer
  * Q' = P'^T P' is formed from (the reference keeps El::gmp::Precision() bits,
- * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here 32 (limbs-2) - 7, or - 3 for the
- * limb counts that use one Karatsuba level): inputs of sdpb_hip_op_int_syrk obey |v| < 2^FB. */
+ * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here FB = 32 FX - 17 from --precision 400 up (Toom-4
+ * image; FX = limbs - 2 rounded up to a multiple of four: 495 bits at 400 and at 512, 751 at 768, 1007 at
+ * 1024) and 32 (limbs-2) - 7 at 128 and 256 bits (two Karatsuba levels)): inputs of sdpb_hip_op_int_syrk
+ * obey |v| < 2^FB. */
 int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx);
 /* Measurement aid (bench/profiling only, never on the solve path): average HIP-event time in
  * ms of `reps` launches of one kernel of the iteration on synthetic device-resident operands.
@@ -184,6 +186,14 @@ const char *sdpb_hip_comm_name(sdpb_hip_ctx *ctx);
  * all-gather of `bytes` bytes and a SUM all-reduce of bytes/8 64-bit lanes through the same
  * code path the solver uses must return the data unchanged.  0 = ok. */
 int sdpb_hip_rccl_selftest(size_t bytes);
+/* The same transport with `world` ranks, outside any solver (collective: every rank calls it with the id rank 0
+ * obtained from sdpb_hip_rccl_unique_id): rank-ordered all-gather, in-place 64-bit SUM all-reduce of `bytes`, and
+ * in-place broadcasts from every root issued alternately from two streams — the three collectives and the stream
+ * pattern the iteration uses in place of the El::mpi calls of restore_and_reduce.cxx:137-212 and of the distributed
+ * El::Cholesky (initialize_schur_complement_solver.cxx:95-103) — each verified against the expected bytes.  A
+ * launcher runs it once in a short-lived process under a timeout (sdpb_amd/rccl_preflight.py) before it hands the
+ * iteration to the in-library exchange.  Returns 0 or 3 with the reason in sdpb_hip_last_error(NULL). */
+int sdpb_hip_rccl_preflight(const char id[SDPB_HIP_RCCL_ID_BYTES], int rank, int world_size, size_t bytes);
 
 /* --maxRuntime (Solver_Parameters.hxx:27): the wall-clock test of
  * compute_feasible_and_termination.cxx:51-56, taken between MaxIterationsExceeded and
@@ -200,6 +210,16 @@ int sdpb_hip_set_profiling(sdpb_hip_ctx *ctx, int on);
 /* Host synchronisation points executed so far (3 per iteration: termination test,
  * corrector centering parameter, step lengths). */
 long sdpb_hip_host_syncs(sdpb_hip_ctx *ctx);
+/* Progress record for a watchdog: the reference's step is collective over COMM_WORLD and a
+ * rank that falls out of step hangs the others inside MPI; here a second host thread may poll this while
+ * sdpb_hip_iterate is running (lock-free, the only entry point with that property besides
+ * sdpb_hip_request_stop).  out[0] iteration, [1] host synchronisation points passed, [2] collectives
+ * enqueued on the exchange so far, [3] 64-bit FNV-1a hash of their (kind, bytes, root) sequence, [4] kind of
+ * the last one (1 all-gather, 2 all-reduce, 3 broadcast), [5] its bytes, [6] its root + 1 (0: rootless),
+ * [7] asynchronous error code of the transport (ncclCommGetAsyncError; 0 none).  The same hash travels in
+ * the result block of every synchronisation point: ranks whose sequences differ ALL fail with code 3
+ * "collective sequence mismatch" (replaces nothing in the reference — MPI offers no such check). */
+int sdpb_hip_progress(sdpb_hip_ctx *ctx, unsigned long long out[8]);
 
 /* Accumulated wall time per stage in ms as a JSON object; names follow the reference's
  * Scoped_Timer hierarchy below "run.iter_*." (SURVEY.md §5). */

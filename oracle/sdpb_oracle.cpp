@@ -23,6 +23,7 @@
 #include <gmp.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -584,6 +585,7 @@ struct Oracle
   F objective_const;
   Params par;
   Mat Q;
+  double seconds_syrk_Q = 0; // wall time spent in syrk_Q so far (bench.py's cpu_baseline leg reports the stage)
   long total_psd_rows = 0;
   // per-iteration outputs (print_iteration.cxx:77-108)
   F primal_objective, dual_objective, duality_gap, primal_error_P,
@@ -931,7 +933,14 @@ void initialize_schur_off_diagonal(Oracle &o)
 // the *semantics* of bigint_syrk_blas (bigint_syrk_blas.cxx:183-302): the
 // exact integer P'^T P' of the truncated, normalised, 2^p-shifted P'
 // (fmpz_BigFloat_convert.hxx:13 -> fmpz_set_mpf truncates toward zero).
+void syrk_Q_body(Oracle &o);
 void syrk_Q(Oracle &o)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  syrk_Q_body(o);
+  o.seconds_syrk_Q += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+void syrk_Q_body(Oracle &o)
 {
   const int N = o.N;
   // GMP reports the rounded-up precision (El::gmp::Precision(), compute_Q.cxx:107)
@@ -1779,6 +1788,7 @@ const char *orc_get_scalar(void *h, const char *name)
   else if(n == "max_block_cond_number") v = &o->max_block_cond_number;
   else if(n == "primalError") { pe = o->primal_error(); v = &pe; }
   else if(n == "block_name") { o->strbuf = o->max_block_cond_number_name; return o->strbuf.c_str(); }
+  else if(n == "seconds.syrk_Q") { o->strbuf = std::to_string(o->seconds_syrk_Q); return o->strbuf.c_str(); }
   else { o->strbuf = ""; return o->strbuf.c_str(); }
   o->strbuf = to_str(*v);
   return o->strbuf.c_str();

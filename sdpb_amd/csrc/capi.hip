@@ -352,6 +352,86 @@ int sdpb_hip_rccl_selftest(size_t bytes)
       return fail(nullptr, 3, e.what());
     }
 }
+// The same transport class with MORE than one rank, outside any solver: what a launcher runs once (in a
+// short-lived process, under a timeout) before it trusts the in-library exchange with the iteration.
+int sdpb_hip_rccl_preflight(const char id[SDPB_HIP_RCCL_ID_BYTES], int rank, int world, size_t bytes)
+{
+  try
+    {
+      if(world < 1 || rank < 0 || rank >= world)
+        return fail(nullptr, 4, "sdpb_hip_rccl_preflight: need 0 <= rank < world");
+      const size_t n = std::max<size_t>(bytes / 8, 1);
+      std::unique_ptr<sdpb::Comm> comm(sdpb::make_rccl_comm(id, SDPB_HIP_RCCL_ID_BYTES, rank, world));
+      if(comm->ranks() != world)
+        return fail(nullptr, 3, "sdpb_hip_rccl_preflight: ncclCommCount disagrees with the world size");
+      auto pattern = [](int r, size_t i) { return 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1) + 0xD1B54A32D192ED03ull * (unsigned long long)(r + 1); };
+      std::vector<unsigned long long> mine(n), back(n), all((size_t)world * n);
+      for(size_t i = 0; i < n; ++i)
+        mine[i] = pattern(rank, i);
+      sdpb::DevBuf<unsigned long long> a, g, m;
+      a.upload(mine);
+      g.alloc((size_t)world * n);
+      m.alloc(n);
+      hipStream_t s1, s2;
+      hipEvent_t ev;
+      HIP_CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+      HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      // 1. all-gather in rank order (result blocks, N-vectors)
+      comm->allgather(a.p, g.p, n * 8, s1);
+      HIP_CHECK(hipMemcpyAsync(all.data(), g.p, (size_t)world * n * 8, hipMemcpyDeviceToHost, s1));
+      HIP_CHECK(hipStreamSynchronize(s1));
+      for(int r = 0; r < world; ++r)
+        for(size_t i = 0; i < n; i += std::max<size_t>(n / 257, 1))
+          if(all[(size_t)r * n + i] != pattern(r, i))
+            return fail(nullptr, 3, "sdpb_hip_rccl_preflight: all-gather returned wrong data");
+      // 2. in-place 64-bit SUM all-reduce (the Q' image); wrapping sums are exact
+      comm->allreduce_sum_u64(a.p, n, s1);
+      HIP_CHECK(hipMemcpyAsync(back.data(), a.p, n * 8, hipMemcpyDeviceToHost, s1));
+      HIP_CHECK(hipStreamSynchronize(s1));
+      for(size_t i = 0; i < n; i += std::max<size_t>(n / 257, 1))
+        {
+          unsigned long long want = 0;
+          for(int r = 0; r < world; ++r)
+            want += pattern(r, i);
+          if(back[i] != want)
+            return fail(nullptr, 3, "sdpb_hip_rccl_preflight: 64-bit all-reduce returned a wrong sum");
+        }
+      // 3. in-place broadcasts from every root, issued alternately from two streams with a dependent kernel-free
+      //    hand-over in between (the panel messages of the distributed Cholesky(Q) come from the chain stream
+      //    while other collectives of the iteration are issued from the main stream)
+      for(int root = 0; root < world; ++root)
+        {
+          hipStream_t st = (root & 1) ? s2 : s1, other = (root & 1) ? s1 : s2;
+          for(size_t i = 0; i < n; ++i)
+            mine[i] = pattern(rank + 7 * (root + 1), i);
+          HIP_CHECK(hipMemcpyAsync(m.p, mine.data(), n * 8, hipMemcpyHostToDevice, st));
+          if(!comm->broadcast(m.p, n * 8, root, st))
+            return fail(nullptr, 3, "sdpb_hip_rccl_preflight: the transport offers no broadcast");
+          HIP_CHECK(hipEventRecord(ev, st));
+          HIP_CHECK(hipStreamWaitEvent(other, ev, 0));
+          HIP_CHECK(hipMemcpyAsync(back.data(), m.p, n * 8, hipMemcpyDeviceToHost, other));
+          HIP_CHECK(hipStreamSynchronize(other));
+          for(size_t i = 0; i < n; i += std::max<size_t>(n / 257, 1))
+            if(back[i] != pattern(root + 7 * (root + 1), i))
+              return fail(nullptr, 3, "sdpb_hip_rccl_preflight: in-place broadcast returned wrong data");
+        }
+      if(comm->async_error() != 0)
+        return fail(nullptr, 3, "sdpb_hip_rccl_preflight: the communicator reports an asynchronous error");
+      (void)hipEventDestroy(ev);
+      (void)hipStreamDestroy(s1);
+      (void)hipStreamDestroy(s2);
+      return 0;
+    }
+  catch(sdpb::SolverError &e)
+    {
+      return fail(nullptr, e.code, e.what());
+    }
+  catch(std::exception &e)
+    {
+      return fail(nullptr, 3, e.what());
+    }
+}
 int sdpb_hip_set_max_runtime(sdpb_hip_ctx *ctx, double seconds)
 {
   return guarded(ctx, [&] { ctx->solver->set_max_runtime(seconds); });
@@ -366,6 +446,15 @@ int sdpb_hip_set_profiling(sdpb_hip_ctx *ctx, int on)
   return guarded(ctx, [&] { ctx->solver->set_profiling(on != 0); });
 }
 long sdpb_hip_host_syncs(sdpb_hip_ctx *ctx) { return ctx ? ctx->solver->host_syncs() : 0; }
+// lock-free by construction (atomics only): no guarded(), no last_error, callable while another thread is inside
+// sdpb_hip_iterate
+int sdpb_hip_progress(sdpb_hip_ctx *ctx, unsigned long long out[8])
+{
+  if(!ctx || !out)
+    return 4;
+  ctx->solver->progress(out);
+  return 0;
+}
 
 int sdpb_hip_timers(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed)
 {

@@ -1197,6 +1197,113 @@ __global__ void __launch_bounds__(QS2_T) k_qsolve_panel2(Batch Q, Batch Linv, mw
   QS_MARK(5);
 }
 
+// Round 4: the same panel step with both sums formed ACROSS the lanes as exact integer sums (mw.hpp: raw terms).
+// In k_qsolve_panel2 a sum of 32 products is 8 + 4 dependent aligned adds (an aligned add costs a lone
+// wavefront ~0.8 us: ~10 us per sum, two sums per launch, 2 N/PB launches per right-hand side, replicated on every
+// GPU).  Here lane (i, k) forms the raw product, the lanes of a row agree on the largest exponent (LDS atomicMax) and
+// on the signs (LDS atomicOr), every lane aligns its product to the window below that exponent and stores the
+// window limb-major; lane (i, l) then adds limb l of the 32 windows of row i as a signed 64-bit integer — 32
+// independent LDS reads instead of a chain of adds — and one lane per row propagates the carries and normalises
+// once.  Integer addition is associative: the result does not depend on lane order or layout (the emulation build
+// gives the same bits by construction).  Slots: forward k PB + i (the row index is the fast lane index, as the
+// loads of Q want), transposed i PB + (k xor i) (writes along k and reads along i both hit 32 distinct banks).
+template <int NL, bool TRANS>
+__global__ void __launch_bounds__(QS2_T) k_qsolve_panel3(Batch Q, Batch Linv, mw::Ptr rhs, mw::Ptr out, int k0)
+{
+  raise_chain_priority();
+  static_assert(PB * PB <= 1024 && (PB & (PB - 1)) == 0, "one lane per (row, column) of a panel; xor slots");
+  constexpr int W = NL + 2, STR = PB * PB;
+  const MatDesc dq = Q.d[0], di = Linv.d[0];
+  const int N = dq.rows, nb = di.rows, t = threadIdx.x;
+  const int ip = TRANS ? t / PB : t % PB, kp = TRANS ? t % PB : t / PB;
+  auto slot = [](int i, int k) { return TRANS ? i * PB + (k ^ i) : k * PB + i; };
+  __shared__ uint32_t win[W * STR], sx[(NL + 2) * PB], smask[PB];
+  __shared__ long long csum[W * PB];
+  __shared__ int semax[PB];
+  const int first = TRANS ? 0 : k0 + nb, count = TRANS ? k0 : N - k0 - nb;
+  const int rp = blockIdx.x * PB + ip;
+  const bool tri = ip < nb && kp < nb && (TRANS ? kp >= ip : kp <= ip), upd = rp < count && kp < nb;
+  const Mw<NL> li = tri ? (TRANS ? mat_ld<NL>(Linv, di, kp, ip) : mat_ld<NL>(Linv, di, ip, kp)) : mw::zero<NL>();
+  const Mw<NL> lq = upd ? (TRANS ? mat_ld<NL>(Q, dq, k0 + kp, first + rp) : mat_ld<NL>(Q, dq, first + rp, k0 + kp)) : mw::zero<NL>();
+  const bool last = t < PB && (int)blockIdx.x * PB + t < count;
+  const Mw<NL> old = last ? mw::load<NL>(rhs, (size_t)first + blockIdx.x * PB + t) : mw::zero<NL>(); // not touched by this launch before its own store
+  if(t < PB)
+    {
+      smem_st<NL, PB>(sx, t, t < nb ? mw::load<NL>(rhs, (size_t)k0 + t) : mw::zero<NL>());
+      semax[t] = mw::EZERO;
+      smask[t] = 0u;
+    }
+  __syncthreads();
+  // sum over k of the terms (P, e, neg) of row ip, for every row: the window of row i ends up in csum[. PB + i]
+  auto rowsum = [&](const uint32_t(&P)[NL + 1], int32_t e, uint32_t neg) __attribute__((always_inline)) {
+    if(e != mw::EZERO)
+      {
+        atomicMax(&semax[ip], e);
+        if(neg)
+          atomicOr(&smask[ip], 1u << kp);
+      }
+    __syncthreads();
+    uint32_t x[W];
+    mw::term_align<NL>(P, e, semax[ip], x);
+#pragma unroll
+    for(int l = 0; l < W; ++l)
+      win[l * STR + slot(ip, kp)] = x[l];
+    __syncthreads();
+    for(int idx = t; idx < W * PB; idx += QS2_T)
+      {
+        const int i = idx % PB, l = idx / PB;
+        const uint32_t m = smask[i];
+        long long c = 0;
+#pragma unroll 8
+        for(int k = 0; k < PB; ++k)
+          {
+            const long long w = (long long)win[l * STR + slot(i, k)];
+            c += ((m >> k) & 1u) ? -w : w;
+          }
+        csum[l * PB + i] = c;
+      }
+    __syncthreads();
+  };
+  // carries of row i -> an accumulator window (two's complement, top limb = headroom)
+  auto window = [&](int i) __attribute__((always_inline)) {
+    Acc<NL> a;
+    long long carry = 0;
+#pragma unroll
+    for(int l = 0; l < W; ++l)
+      {
+        const long long v = csum[l * PB + i] + carry;
+        a.w[l] = (uint32_t)v;
+        carry = v >> 32;
+      }
+    a.etop = semax[i];
+    return a;
+  };
+  uint32_t P[NL + 1], neg;
+  int32_t e;
+  // xp = Linv_pp rhs_p (lower triangular; TRANS: its transpose)
+  mw::term_mul<NL>(li, smem_ld<NL, PB>(sx, kp), P, e, neg);
+  rowsum(P, e, neg);
+  if(t < PB)
+    {
+      const Mw<NL> xp = mw::acc_result(window(t));
+      smem_st<NL, PB>(sx, t, xp); // every lane read its sx[kp] before the barriers of rowsum
+      if(blockIdx.x == 0 && t < nb)
+        mw::store<NL>(out, (size_t)k0 + t, xp);
+      semax[t] = mw::EZERO;
+      smask[t] = 0u;
+    }
+  __syncthreads();
+  // rows outside the panel: rhs[r] -= sum_k L(r, k0 + k) xp[k]
+  mw::term_mul<NL>(lq, smem_ld<NL, PB>(sx, kp), P, e, neg);
+  rowsum(P, e, neg ^ 1u);
+  if(last)
+    {
+      Acc<NL> a = window(t);
+      mw::acc_add(a, old);
+      mw::store<NL>(rhs, (size_t)first + blockIdx.x * PB + t, mw::acc_result(a));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Block-structure helpers shared by the SDP-specific kernels
 // ---------------------------------------------------------------------------
@@ -1269,7 +1376,11 @@ __global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Bat
       // A_X_inv tile [cb][rb](r,c) = AX(cb K + r, rb K + c)  (compute_A_X_inv.cxx:39-56)
       // A_Y tile     [cb][rb](r,c) = AY(cb K + c, rb K + r)  (compute_A_Y.cxx:47-64)
 #define AXT(cb, rb) mat_ld<NL>(AX, dx, (cb)*K + row, (rb)*K + col)
-#define AYT(cb, rb) mat_ld<NL>(AY, dy, (cb)*K + col, (rb)*K + row)
+      // A_Y is formed as a symmetric product (k_gemm sym = 1: lower tiles computed and mirrored, as El::Syrk +
+      // MakeSymmetric in compute_A_Y.cxx:35,45), so AY(cb K + c, rb K + r) and AY(rb K + r, cb K + c) are the same
+      // bits; the second form runs along `row`, the fast lane index: one cache line per word plane instead of one
+      // per lane (round 4)
+#define AYT(cb, rb) mat_ld<NL>(AY, dy, (rb)*K + row, (cb)*K + col)
       mw::acc_fma(es, AXT(c0, r1), AYT(c1, r0));
       mw::acc_fma(es, AXT(r0, r1), AYT(c1, c0));
       mw::acc_fma(es, AXT(c0, c1), AYT(r1, r0));
@@ -3241,7 +3352,7 @@ __global__ void __launch_bounds__(WG)
   if(i == j && !mw::is_zero(ni))
     {
       const Mw<NL> diff = mw::abs(mw::sub(v, mw::from_u32<NL>(1)));
-      if(!mw::is_zero(diff) && diff.e > -16 * FX)
+      if(!mw::is_zero(diff) && diff.e > -16 * (NL - 2)) // the reference's 2^-(precision/2), precision = 64 (l - 1) = 32 (NL - 2): not the padded image width FX
         atomicMax(diag_fail, i + 1);
     }
   v = mw::mul(mw::mul(v, ni), mw::load<NL>(norms, j));
@@ -3609,6 +3720,14 @@ template <int NL> __global__ void k_store_scalar(mw::Ptr p, size_t idx, Mw<NL> v
     mw::store<NL>(p, idx, v);
 }
 
+template <int UNUSED = 0> __global__ void k_store_words2(uint32_t *p, uint32_t w0, uint32_t w1)
+{
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      p[0] = w0;
+      p[1] = w1;
+    }
+}
 template <int UNUSED = 0> __global__ void k_store_words4(uint32_t *p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
   if(blockIdx.x == 0 && threadIdx.x == 0)
@@ -3633,13 +3752,21 @@ enum XOp : int
   X_ARGMAX // value of the first rank holding the maximum; extra word XW_TAG follows the winner
 };
 constexpr int X_MAXSLOTS = 24;
-constexpr int X_EXTRA = 4;
+constexpr int X_EXTRA = 7;
 enum XWord : int
 {
   XW_FAIL = 0, // smallest failure tag (0xffffffff = none): every rank raises the same error
   XW_STOP,     // rank 0's wall-clock / signal decision (compute_feasible_and_termination.cxx broadcasts rank 0's)
   XW_OR,       // OR of per-rank flags (SIGTERM received anywhere, run.cxx:332-336)
-  XW_TAG       // which matrix holds the largest Cholesky condition number
+  XW_TAG,      // which matrix holds the largest Cholesky condition number
+  // Collective-sequence self-check: every rank hashes the (kind, bytes, root) of every collective it has
+  // enqueued since the communicator was attached (solver.hpp: note_collective) and deposits the 64-bit hash
+  // here before each all-gather of the result block; k_combine_slots compares the hashes of all ranks and
+  // writes 1 + the first rank that disagrees with rank 0 into XW_SEQBAD (0 = all agree), so that every rank
+  // raises the same error at the same synchronisation point instead of computing on mismatched messages.
+  XW_SEQ_LO,
+  XW_SEQ_HI,
+  XW_SEQBAD
 };
 struct XOps
 {
@@ -3682,9 +3809,14 @@ template <int NL> __global__ void __launch_bounds__(64) k_combine_slots(const ui
           f = fk < f ? fk : f;
           o |= recv[(size_t)k * blk + xoff + XW_OR];
         }
+      uint32_t bad = 0;
+      for(int k = world - 1; k >= 1; --k)
+        if(recv[(size_t)k * blk + xoff + XW_SEQ_LO] != recv[xoff + XW_SEQ_LO] || recv[(size_t)k * blk + xoff + XW_SEQ_HI] != recv[xoff + XW_SEQ_HI])
+          bad = (uint32_t)k + 1u;
       local[xoff + XW_FAIL] = f;
       local[xoff + XW_STOP] = recv[xoff + XW_STOP];
       local[xoff + XW_OR] = o;
+      local[xoff + XW_SEQBAD] = bad;
     }
 }
 // out[i] = sum over ranks (rank order) of the gathered n-vectors; out has stride n

@@ -695,6 +695,54 @@ template <int NL> MW_HD void acc_fma(Acc<NL> &acc, const Mw<NL> &a, const Mw<NL>
   acc_add_raw<NL>(acc, P, a.e + b.e, a.neg ^ b.neg ^ (negate & 1u));
 }
 template <int NL> MW_HD void acc_fms(Acc<NL> &acc, const Mw<NL> &a, const Mw<NL> &b) { acc_fma(acc, a, b, 1u); }
+// ---- raw terms: the pieces of acc_fma for sums that are formed ACROSS lanes ------------------------------
+// A term is an (NL+1)-limb magnitude P, an exponent e and a sign: value = (-1)^neg P / 2^(32(NL+1)) 2^e (what
+// acc_add_raw takes).  A workgroup that sums many terms per output lets every lane form ONE term, agrees on the
+// largest exponent E of the output's terms, aligns every term to the window below E (term_align: exactly the shift
+// acc_add_raw applies, so a term is truncated at 2^-(32(NL+1)) relative to the largest one) and adds the windows
+// limb by limb as integers — associative, hence independent of the order and of the lane layout; carries are
+// propagated once per output (kernels.hpp: the Q substitution).
+template <int NL> MW_HD void term_mul(const Mw<NL> &a, const Mw<NL> &b, uint32_t (&P)[NL + 1], int32_t &e, uint32_t &neg)
+{
+  if(a.e == EZERO || b.e == EZERO)
+    {
+#pragma unroll
+      for(int i = 0; i <= NL; ++i)
+        P[i] = 0;
+      e = EZERO;
+      neg = 0;
+      return;
+    }
+  uint32_t r[NL + 1];
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+  if constexpr(NL >= 2)
+    {
+      mac_column<0, NL - 2, NL - 2>(lo, hi, a.m, b.m);
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+  MulColumns<NL, NL - 1>::run(a.m, b.m, lo, hi, r);
+#pragma unroll
+  for(int i = 0; i < NL; ++i)
+    P[i] = r[i];
+  P[NL] = (uint32_t)lo;
+  e = a.e + b.e;
+  neg = a.neg ^ b.neg;
+}
+// the (NL+2)-limb window of a term below the top exponent E >= e (magnitude; the sign is kept by the caller)
+template <int NL> MW_HD void term_align(const uint32_t (&P)[NL + 1], int32_t e, int32_t E, uint32_t (&x)[NL + 2])
+{
+  const uint32_t d = (uint32_t)(E - e);
+  const bool gone = e == EZERO || d >= 32u * (NL + 1);
+#pragma unroll
+  for(int i = 0; i <= NL; ++i)
+    x[i] = gone ? 0u : P[i];
+  x[NL + 1] = 0;
+  const uint32_t dd = gone ? 0u : d;
+  shr_limbs<NL + 2, true>(x, dd >> 5);
+  shr_bits<NL + 2>(x, dd & 31u);
+}
 // acc += x (negate: acc -= x)
 template <int NL> MW_HD void acc_add(Acc<NL> &acc, const Mw<NL> &x, uint32_t negate = 0)
 {

@@ -52,6 +52,13 @@ struct RcclComm : Comm
     return true;
   }
   const char *name() const override { return "rccl"; }
+  int async_error() const override
+  {
+    ncclResult_t r = ncclSuccess;
+    if(!comm || ncclCommGetAsyncError(comm, &r) != ncclSuccess)
+      return -1;
+    return (int)r;
+  }
   int ranks() const override
   {
     int n = 0;

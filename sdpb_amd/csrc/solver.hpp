@@ -56,6 +56,9 @@ struct Comm
   // in-place broadcast of `bytes` from rank `root`; false = not offered by this transport (the caller
   // then emulates it with an all-gather)
   virtual bool broadcast(void *, size_t, int, hipStream_t) { return false; }
+  // asynchronous error state of the transport (RCCL: ncclCommGetAsyncError; 0 = none / not offered); safe to
+  // call from another thread while the iteration thread waits on a stream (the bench watchdog does)
+  virtual int async_error() const { return 0; }
 };
 struct CallbackComm : Comm
 {
@@ -188,6 +191,7 @@ public:
   virtual void set_max_runtime(double seconds) = 0;
   virtual void request_stop() = 0;
   virtual long host_syncs() const = 0;
+  virtual void progress(unsigned long long out[8]) const = 0;
   virtual std::string timers_json() = 0;
   virtual int limbs() const = 0;
   virtual int fx_frac_bits() const = 0;
@@ -200,11 +204,19 @@ public:
   virtual std::string op_syrk_Q(int rows, int cols, const char *P_colmajor) = 0;
 };
 
+// kernel launches of this process (all solvers): the latency floor of a small SDP is launches x dispatch cost,
+// bench.py reports launches per iteration next to the host synchronisation points
+inline std::atomic<unsigned long long> &launch_counter()
+{
+  static std::atomic<unsigned long long> n{0};
+  return n;
+}
 template <class... KArgs, class... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args &&...args)
 {
   if(grid.x == 0 || grid.y == 0 || grid.z == 0)
     return;
+  launch_counter().fetch_add(1, std::memory_order_relaxed);
   hipLaunchKernelGGL(kernel, grid, block, 0, stream, std::forward<Args>(args)...);
   HIP_CHECK(hipGetLastError());
 }
@@ -312,15 +324,48 @@ template <int NL> class Solver : public SolverBase
   DevBuf<uint32_t> qpanel_msg_, qpanel_gather_; // panel message of the distributed Cholesky(Q) (+ all-gather emulation of its broadcast)
   // Cholesky(Q) distributed over the ranks (1-D block-cyclic over column panels, one broadcast per panel:
   // SURVEY.md §8e; the reference factors Q over all ranks too, initialize_schur_complement_solver.cxx:95-103)
-  // instead of replicated.  Default: from N = 1536 up, where the N^3/3 trailing updates outweigh the
-  // per-panel broadcasts (C5-class); SDPB_HIP_DIST_CHOLQ=0/1 overrides.
+  // instead of replicated.  Opt-in with SDPB_HIP_DIST_CHOLQ=1 (worthwhile from N ~ 1536 up, where the N^3/3
+  // trailing updates outweigh the per-panel broadcasts: C5-class); replicated otherwise.
   bool dist_cholq_ = false;
   long xc_broadcast_calls_ = 0;
   double xc_broadcast_bytes_ = 0;
   DevBuf<uint32_t> resbuf_, xgather_, zero_piece_; // zero_piece_: what k_syrk_fx2 stages for rows/columns outside the image
   std::vector<M> res_host_ = std::vector<M>(R_COUNT);
-  uint32_t xw_host_[X_EXTRA] = {0xffffffffu, 0, 0, 0};
+  uint32_t xw_host_[X_EXTRA] = {0xffffffffu, 0, 0, 0, 0, 0, 0};
   std::unique_ptr<Comm> comm_;
+  // Collective-sequence self-check and progress record (kernels.hpp: XW_SEQ_LO).  Every collective this rank
+  // hands to the transport is folded into a running 64-bit FNV-1a hash of (kind, bytes, root); the hash
+  // travels in the result block and k_combine_slots compares the ranks' values at every synchronisation
+  // point.  The atomics are also what sdpb_hip_progress reads from a watchdog thread while the iteration
+  // thread sits in a stream synchronisation behind a collective that never completes.
+  enum CollKind : unsigned
+  {
+    COLL_ALLGATHER = 1,
+    COLL_ALLREDUCE = 2,
+    COLL_BROADCAST = 3
+  };
+  std::atomic<unsigned long long> seq_hash_{0xcbf29ce484222325ull}, seq_count_{0}, seq_last_kind_{0}, seq_last_bytes_{0},
+    seq_last_root_{0}, prog_iteration_{0}, prog_syncs_{0};
+  // Q substitution with lane-parallel exact sums (k_qsolve_panel3, round 4); SDPB_HIP_QSOLVE_SUM_LANES=0 runs the
+  // round-3 kernel (k_qsolve_panel2: 8 + 4 dependent aligned adds per sum) for A/B measurements
+  bool qsolve_sum_lanes_ = true;
+  int seq_fault_rank_ = -1; // SDPB_HIP_TEST_SEQ_FAULT=r: rank r perturbs its hash (test of the mismatch path)
+  void note_collective(unsigned kind, size_t bytes, int root)
+  {
+    unsigned long long h = seq_hash_.load(std::memory_order_relaxed);
+    const unsigned long long words[3] = {kind, (unsigned long long)bytes, (unsigned long long)(root + 1)};
+    for(unsigned long long w : words)
+      for(int b = 0; b < 8; ++b)
+        {
+          h ^= (w >> (8 * b)) & 0xffu;
+          h *= 0x100000001b3ull;
+        }
+    seq_hash_.store(h, std::memory_order_relaxed);
+    seq_last_kind_.store(kind, std::memory_order_relaxed);
+    seq_last_bytes_.store(bytes, std::memory_order_relaxed);
+    seq_last_root_.store((unsigned long long)(root + 1), std::memory_order_relaxed);
+    seq_count_.fetch_add(1, std::memory_order_release);
+  }
   // what this rank handed to the exchange (bench.py: proof that N ranks exchanged, and how much)
   long xc_allgather_calls_ = 0, xc_allreduce_calls_ = 0;
   double xc_allgather_bytes_ = 0, xc_allreduce_bytes_ = 0;
@@ -495,6 +540,20 @@ public:
   void set_max_runtime(double seconds) override { max_runtime_s_ = seconds; }
   void request_stop() override { stop_requested_.store(1); } // async-signal-safe: a SIGTERM handler may call it
   long host_syncs() const override { return host_syncs_; }
+  // [0] iteration, [1] host synchronisation points passed, [2] collectives enqueued, [3] sequence hash,
+  // [4] kind of the last collective (1 all-gather, 2 all-reduce, 3 broadcast), [5] its bytes, [6] its root + 1
+  // (0 = rootless), [7] the transport's asynchronous error code.  Lock-free: callable from any thread.
+  void progress(unsigned long long out[8]) const override
+  {
+    out[0] = prog_iteration_.load();
+    out[1] = prog_syncs_.load();
+    out[2] = seq_count_.load(std::memory_order_acquire);
+    out[3] = seq_hash_.load();
+    out[4] = seq_last_kind_.load();
+    out[5] = seq_last_bytes_.load();
+    out[6] = seq_last_root_.load();
+    out[7] = comm_ ? (unsigned long long)comm_->async_error() : 0ull;
+  }
   int terminate_reason() const override { return terminate_reason_; }
 
 private:
@@ -654,7 +713,13 @@ private:
       profile_ = std::atoi(e) != 0;
     if(const char *e = std::getenv("SDPB_HIP_OVERLAP_SYRK"))
       overlap_syrk_ = std::atoi(e) != 0;
-    dist_cholq_ = world_ > 1 && N_ >= 1536;
+    if(const char *e = std::getenv("SDPB_HIP_TEST_SEQ_FAULT"))
+      seq_fault_rank_ = std::atoi(e);
+    if(const char *e = std::getenv("SDPB_HIP_QSOLVE_SUM_LANES"))
+      qsolve_sum_lanes_ = std::atoi(e) != 0;
+    // opt-in (round-3 advisor): the production transport of its panel messages, ncclBroadcast, has not yet
+    // run with more than one rank on hardware; the replicated factorisation uses no collective at all
+    dist_cholq_ = false;
     if(const char *e = std::getenv("SDPB_HIP_DIST_CHOLQ"))
       dist_cholq_ = world_ > 1 && std::atoi(e) != 0;
     if(dist_cholq_)
@@ -741,12 +806,13 @@ public:
        << ", \"kernel.k_syrk_fx.limb_macs\": "
        << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TOOM4 ? 7.0 / 16 : SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 7 or 9 (FX/4)^2, or 3 (FX/2)^2 per product
        << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TOOM4 ? 0 : SYRK_TWO_LEVEL ? 2 : 1) << ", \"kernel.k_syrk_fx.toom4\": " << (SYRK_TOOM4 ? 1 : 0)
-       << ", \"host_syncs\": " << host_syncs_
+       << ", \"host_syncs\": " << host_syncs_ << ", \"launches\": " << launch_counter().load()
        << ", \"iterations\": " << iteration_ << ", \"comm.world\": " << world_ << ", \"comm.ranks\": " << (comm_ ? comm_->ranks() : (world_ == 1 ? 1 : 0))
        << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
        << ", \"comm.allgather_bytes\": " << xc_allgather_bytes_ << ", \"comm.allreduce_calls\": " << xc_allreduce_calls_
        << ", \"comm.allreduce_bytes\": " << xc_allreduce_bytes_ << ", \"comm.broadcast_calls\": " << xc_broadcast_calls_
-       << ", \"comm.broadcast_bytes\": " << xc_broadcast_bytes_ << ", \"comm.cholesky_Q\": " << (dist_cholq_ ? "\"distributed\"" : "\"replicated\"");
+       << ", \"comm.broadcast_bytes\": " << xc_broadcast_bytes_ << ", \"comm.cholesky_Q\": " << (dist_cholq_ ? "\"distributed\"" : "\"replicated\"")
+       << ", \"comm.collectives\": " << seq_count_.load() << ", \"comm.sequence_hash\": \"" << std::hex << seq_hash_.load() << std::dec << "\"";
     ss << "}";
     return ss.str();
   }
@@ -972,6 +1038,13 @@ private:
       ops.op[so.first] = so.second;
     xc_allgather_calls_ += 1;
     xc_allgather_bytes_ += (double)(RES_WORDS * sizeof(uint32_t));
+    note_collective(COLL_ALLGATHER, RES_WORDS * sizeof(uint32_t), -1);
+    {
+      unsigned long long h = seq_hash_.load();
+      if(seq_fault_rank_ == rank_)
+        h ^= 1ull;
+      launch(k_store_words2<0>, dim3(1), dim3(64), stream_, xwords() + XW_SEQ_LO, (uint32_t)h, (uint32_t)(h >> 32));
+    }
     comm().allgather(resbuf_.p, xgather_.p, RES_WORDS * sizeof(uint32_t), stream_);
     launch(k_combine_slots<NL>, dim3(1), dim3(64), stream_, (const uint32_t *)xgather_.p, world_, (int)R_COUNT, ops, resbuf_.p);
   }
@@ -982,6 +1055,7 @@ private:
     HIP_CHECK(hipMemcpyAsync(h, resbuf_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
     host_syncs_ += 1;
+    prog_syncs_.store((unsigned long long)host_syncs_);
     for(int i = 0; i < R_COUNT; ++i)
       {
         const uint32_t hd = h[i];
@@ -997,6 +1071,19 @@ private:
   // the reference's RUNTIME_ERRORs, from the smallest failure tag of all ranks
   void throw_if_failed(unsigned max_stage)
   {
+    if(world_ > 1 && xw_host_[XW_SEQBAD])
+      {
+        // the ranks did not enqueue the same collectives: whatever was exchanged since the last agreeing
+        // synchronisation point is meaningless; every rank sees the same words and raises the same error
+        (void)hipStreamSynchronize(stream_q_);
+        (void)hipStreamSynchronize(stream_q2_);
+        q_pending_ = false;
+        std::ostringstream ss;
+        ss << "collective sequence mismatch: rank " << (xw_host_[XW_SEQBAD] - 1) << " and rank 0 enqueued different (kind, bytes, root) "
+           << "sequences on the exchange before synchronisation point " << host_syncs_ << " of iteration " << iteration_
+           << " (this rank: " << seq_count_.load() << " collectives)";
+        throw HipError(3, ss.str());
+      }
     const uint32_t tag = xw_host_[XW_FAIL];
     if(tag == 0xffffffffu || (tag >> 27) > max_stage)
       return;
@@ -1040,6 +1127,7 @@ private:
       }
     xc_allgather_calls_ += 1;
     xc_allgather_bytes_ += (double)(words * sizeof(uint32_t));
+    note_collective(COLL_ALLGATHER, words * sizeof(uint32_t), -1);
     comm().allgather(a.base, xgather_.p, words * sizeof(uint32_t), stream_);
     launch(k_combine_vec<NL>, dim3(cdiv(count, WG)), dim3(WG), stream_, (const uint32_t *)xgather_.p, world_, (int)count, a.ptr());
   }
@@ -1509,6 +1597,7 @@ private:
     launch(k_widen_tri_u64<0>, grid, dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_, (int)ACCW, acc64_.p);
     xc_allreduce_calls_ += 1;
     xc_allreduce_bytes_ += (double)(T * ACCW * 8);
+    note_collective(COLL_ALLREDUCE, T * ACCW * 8, -1);
     comm().allreduce_sum_u64(acc64_.p, T * ACCW, stream_);
     launch(k_narrow_tri_carry<0>, grid, dim3(WG), stream_, (const unsigned long long *)acc64_.p, N_, (int)ACCW, acc_.p, acc_stride_);
   }
@@ -1518,6 +1607,7 @@ private:
     const size_t bytes = words * sizeof(uint32_t);
     xc_broadcast_calls_ += 1;
     xc_broadcast_bytes_ += (double)bytes;
+    note_collective(COLL_BROADCAST, bytes, root);
     if(comm().broadcast(buf, bytes, root, stream_))
       return;
     if(qpanel_gather_.n < words * world_)
@@ -1529,44 +1619,82 @@ private:
     if(root != rank_)
       HIP_CHECK(hipMemcpyAsync(buf, qpanel_gather_.p + (size_t)root * words, bytes, hipMemcpyDeviceToDevice, stream_));
   }
-  // Cholesky(Q) over all ranks: column panel p belongs to rank p % world.  Step p: the owner factors and
-  // inverts the diagonal block, solves the rows below it and broadcasts the finished panel (with the
-  // inverted block and its failure flag); every rank then applies the panel to the column panels IT owns.
-  // Each rank ends with the whole factor (it received every panel), so the Q solves stay as they are.
-  // The N^3/3 trailing updates divide by the number of ranks; the chain of diagonal blocks does not.
-  // Runs on the main stream: its collectives stay ordered with the others of the iteration.
+  // Cholesky(Q) over all ranks (the reference factors Q over COMM_WORLD too, initialize_schur_complement_solver.cxx:
+  // 95-103): column panel p belongs to rank p % world.  Step p: the owner factors and inverts the diagonal block,
+  // solves the rows below it and broadcasts the finished panel (with the inverted block and its failure flag);
+  // every rank then applies the panel to the column panels IT owns.  Each rank ends with the whole factor (it
+  // received every panel), so the Q solves stay as they are.  The N^3/3 trailing updates divide by the number of
+  // ranks; the chain of diagonal blocks does not.
+  //
+  // One-panel look-ahead on two side streams (round 4; the shape of blocked_cholesky_lookahead):
+  //   chain stream S (stream_q_):  broadcast(p) -> unpack(p) -> [owner of p+1: update panel p+1 with panel p,
+  //                                factor + invert its diagonal block, solve its rows, pack(p+1)] -> broadcast(p+1) ...
+  //   bulk stream B (stream_q2_):  wait panel p -> update the other owned panels q > p with panel p
+  // so the diagonal block of panel p+1 (a dependent chain on one CU) is factored while this rank's bulk of step p
+  // runs, and the main stream goes on with the residues and the Q-independent part of the predictor until
+  // join_cholesky_Q().  Panel p+1 at step p needs the updates of panels < p, which ran on B: S waits for B's
+  // event of step p-1.  Every panel is computed by its owner only, so all ranks hold identical bits.  The
+  // broadcasts are issued from S; the host issues every collective of the iteration in the same program order on
+  // every rank, which is what the one communicator requires (RCCL orders its kernels in issue order across the
+  // streams it is used from; the callback transport synchronises S and calls the host collective at once).
   void cholesky_Q_distributed()
   {
     int *qflags = flags_.p + 2 * std::max(Jl_, 1);
     const Batch A = QB(), invd = vecQB(invdQ_), Li{LiQ_.ptr(), d_Q_.p, 1};
     const int panels = cdiv(N_, PB);
+    constexpr int TPP = PB >= 16 ? PB / 16 : 1;
+    hipStream_t S = stream_q_, B = stream_q2_;
+    HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
+    HIP_CHECK(hipStreamWaitEvent(S, ev_q_ready_, 0));
+    HIP_CHECK(hipStreamWaitEvent(B, ev_q_ready_, 0));
+    auto factor_and_pack = [&](int p) { // the owner's part of panel p, on S
+      const int k0 = PB * p, nb = std::min(PB, N_ - k0), rows = N_ - k0;
+      const size_t cnt = (size_t)rows * nb + (size_t)nb * nb + nb;
+      launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), S, A, invd, Li, p, qflags, (unsigned long long *)nullptr);
+      const int below = N_ - PB * (p + 1), above = PB * p;
+      if(std::max(below, above) > 0)
+        launch(k_chol_panel_solve<NL>, dim3(cdiv(std::max(below, above), TR), 1), dim3(WG), S, A, Li, p, 0, (unsigned long long *)nullptr);
+      launch(k_qpanel_pack<NL>, dim3(cdiv(cnt, WG)), dim3(WG), S, A, Li, invd, p, (const int *)qflags, qpanel_msg_.p);
+    };
+    if(rank_ == 0)
+      factor_and_pack(0);
     for(int p = 0; p < panels; ++p)
       {
         const int owner = p % world_, k0 = PB * p, nb = std::min(PB, N_ - k0), rows = N_ - k0;
         const size_t cnt = (size_t)rows * nb + (size_t)nb * nb + nb, words = cnt * (NL + 1) + 1;
-        if(owner == rank_)
-          {
-            launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), stream_, A, invd, Li, p, qflags, (unsigned long long *)nullptr);
-            const int below = N_ - PB * (p + 1), above = PB * p;
-            if(std::max(below, above) > 0)
-              launch(k_chol_panel_solve<NL>, dim3(cdiv(std::max(below, above), TR), 1), dim3(WG), stream_, A, Li, p, 0, (unsigned long long *)nullptr);
-            launch(k_qpanel_pack<NL>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, A, Li, invd, p, (const int *)qflags, qpanel_msg_.p);
-          }
-        xbroadcast(qpanel_msg_.p, words, owner);
+        {
+          OnSideStream on_chain(this); // stream_ = S for the message
+          xbroadcast(qpanel_msg_.p, words, owner);
+        }
         if(owner != rank_)
-          launch(k_qpanel_unpack<NL>, dim3(cdiv(std::max(cnt, (size_t)k0 * nb), WG)), dim3(WG), stream_, A, Li, invd, p, qflags, (const uint32_t *)qpanel_msg_.p);
-        // owned panels q > p: q = rank (mod world)
+          launch(k_qpanel_unpack<NL>, dim3(cdiv(std::max(cnt, (size_t)k0 * nb), WG)), dim3(WG), S, A, Li, invd, p, qflags, (const uint32_t *)qpanel_msg_.p);
+        HIP_CHECK(hipEventRecord(ev_la_strip_, S)); // panel p is in place on this rank
+        const int Mrows = N_ - (k0 + nb);
+        const bool own_next = p + 1 < panels && (p + 1) % world_ == rank_;
+        if(own_next)
+          {
+            if(p >= 1)
+              HIP_CHECK(hipStreamWaitEvent(S, ev_la_bulk_, 0)); // panels < p have been applied to panel p+1 (on B)
+            launch(k_chol_syrk_cols<NL>, dim3(cdiv(Mrows, 16), TPP), dim3(WG), S, A, p, p + 1, world_, 1);
+            factor_and_pack(p + 1);
+          }
+        HIP_CHECK(hipStreamWaitEvent(B, ev_la_strip_, 0));
+        // the other owned panels q > p: q = rank (mod world)
         int q0 = p + 1;
         while(q0 % world_ != rank_)
           ++q0;
+        if(own_next)
+          q0 += world_;
         if(q0 < panels)
           {
-            const int count = (panels - 1 - q0) / world_ + 1, M = N_ - (k0 + nb);
-            constexpr int TPP = PB >= 16 ? PB / 16 : 1;
-            launch(k_chol_syrk_cols<NL>, dim3(cdiv(M, 16), count * TPP), dim3(WG), stream_, A, p, q0, world_, count);
+            const int count = (panels - 1 - q0) / world_ + 1;
+            launch(k_chol_syrk_cols<NL>, dim3(cdiv(Mrows, 16), count * TPP), dim3(WG), B, A, p, q0, world_, count);
           }
+        HIP_CHECK(hipEventRecord(ev_la_bulk_, B));
       }
-    launch(k_fail_tags_q<0>, dim3(1), dim3(64), stream_, (const int *)qflags, xwords() + XW_FAIL);
+    // B has waited for the last panel on S and S queues nothing after it: B's tail orders the whole factor
+    HIP_CHECK(hipEventRecord(ev_q_done_, B));
+    q_pending_ = true;
   }
   // El::Cholesky(UPPER,Q) (initialize_schur_complement_solver.cxx:95-103), stored here
   // as the lower factor L = U^T (blocked, see kernels.hpp).  The factorisation is a long
@@ -1635,8 +1763,12 @@ private:
           const int k0 = p * q_nb_, nb = std::min(q_nb_, N_ - k0), rest = N_ - k0 - nb;
           Batch iv{LiQ_.ptr(), d_qdiag_.p + p, 1};
           if constexpr(PB * PB <= 1024)
-            launch(k_qsolve_panel2<NL, false>, dim3(std::max(1u, cdiv(rest, PB))), dim3(QS2_T), stream_, QB(), iv, dy_.ptr(), qtmpv_.ptr(),
-                   k0);
+            {
+              if(qsolve_sum_lanes_)
+                launch(k_qsolve_panel3<NL, false>, dim3(std::max(1u, cdiv(rest, PB))), dim3(QS2_T), stream_, QB(), iv, dy_.ptr(), qtmpv_.ptr(), k0);
+              else
+                launch(k_qsolve_panel2<NL, false>, dim3(std::max(1u, cdiv(rest, PB))), dim3(QS2_T), stream_, QB(), iv, dy_.ptr(), qtmpv_.ptr(), k0);
+            }
           else
             launch(k_qsolve_panel<NL, false>, dim3(std::max(1u, cdiv(rest, QS_ROWS))), dim3(WG), stream_, QB(), iv, dy_.ptr(),
                    qtmpv_.ptr(), k0);
@@ -1646,7 +1778,12 @@ private:
           const int k0 = p * q_nb_;
           Batch iv{LiQ_.ptr(), d_qdiag_.p + p, 1};
           if constexpr(PB * PB <= 1024)
-            launch(k_qsolve_panel2<NL, true>, dim3(std::max(1u, cdiv(k0, PB))), dim3(QS2_T), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(), k0);
+            {
+              if(qsolve_sum_lanes_)
+                launch(k_qsolve_panel3<NL, true>, dim3(std::max(1u, cdiv(k0, PB))), dim3(QS2_T), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(), k0);
+              else
+                launch(k_qsolve_panel2<NL, true>, dim3(std::max(1u, cdiv(k0, PB))), dim3(QS2_T), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(), k0);
+            }
           else
             launch(k_qsolve_panel<NL, true>, dim3(std::max(1u, cdiv(k0, QS_ROWS))), dim3(WG), stream_, QB(), iv, qtmpv_.ptr(), dy_.ptr(),
                    k0);
@@ -1904,6 +2041,7 @@ public:
         start_time_ = std::chrono::steady_clock::now();
       }
     iteration_ += 1;
+    prog_iteration_.store((unsigned long long)iteration_);
     leave_beside_stream();
     Timer whole(this, "iteration");
     if(profile_)

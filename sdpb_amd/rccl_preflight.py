@@ -1,0 +1,117 @@
+"""Pre-flight of the in-library RCCL exchange with more than one rank, in short-lived child processes.
+
+The library's own communicator (csrc/rccl_comm.hpp: ncclAllGather / ncclAllReduce / ncclBroadcast on the
+library's streams) replaces the El::mpi collectives of the reference's step (restore_and_reduce.cxx:137-212,
+initialize_schur_complement_solver.cxx:95-103).  A launcher that is about to hand the iteration to it first lets
+every rank run `sdpb_hip_rccl_preflight` (include/sdpb_hip.h) in a CHILD process under a timeout: a bootstrap that
+cannot connect, a collective that never completes or wrong bytes then cost a few seconds and a clear record
+instead of a hung job, and the launcher can fall back to its own collectives (sdpb_hip_set_collectives).
+
+Child:   python -m sdpb_amd.rccl_preflight --rank R --world W --device D [--id HEX] [--bytes B]
+         rank 0 without --id creates the id and prints "ID <hex>" first; every child ends with "PREFLIGHT OK {...}".
+Parent:  run(rank, world, device, exchange_id, timeout) -> record; exchange_id(hex or None) -> hex is the launcher's
+         way to move 128 bytes from rank 0 to everybody (torch.distributed, MPI_Bcast, a file).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child(args) -> int:
+    from sdpb_amd.solver import load_library
+    import torch  # the library binds to torch's HIP runtime / RCCL (solver.load_library imports it first as well)
+    torch.cuda.set_device(args.device)
+    torch.cuda.synchronize()
+    L = load_library(args.lib)
+    L.sdpb_hip_rccl_preflight.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+    L.sdpb_hip_last_error.restype = ctypes.c_char_p
+    if args.id:
+        uid = bytes.fromhex(args.id)
+    else:
+        buf = ctypes.create_string_buffer(128)
+        if L.sdpb_hip_rccl_unique_id(buf) != 0:
+            print("PREFLIGHT FAILED unique id: " + L.sdpb_hip_last_error(None).decode(), flush=True)
+            return 3
+        uid = buf.raw
+        print("ID " + uid.hex(), flush=True)
+    t0 = time.time()
+    rc = L.sdpb_hip_rccl_preflight(uid, args.rank, args.world, args.bytes)
+    if rc != 0:
+        print("PREFLIGHT FAILED " + L.sdpb_hip_last_error(None).decode(), flush=True)
+        return 3
+    print("PREFLIGHT OK " + json.dumps({"rank": args.rank, "world": args.world, "bytes": args.bytes,
+                                        "seconds": round(time.time() - t0, 3)}), flush=True)
+    return 0
+
+
+def run(rank: int, world: int, device: int, exchange_id, timeout: float = 120.0, nbytes: int = 64 << 20,
+        lib_path: str | None = None) -> dict:
+    """One rank's part of the pre-flight: start the child, move rank 0's id through `exchange_id`, wait.
+    Returns {"ok": bool, "seconds": s, "detail": str}.  Never raises for a failing or hanging child."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):   # the child is not a torchrun worker
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "sdpb_amd.rccl_preflight", "--rank", str(rank), "--world", str(world),
+           "--device", str(device), "--bytes", str(nbytes)]
+    if lib_path:
+        cmd += ["--lib", lib_path]
+    t0 = time.time()
+    deadline = t0 + timeout
+    child, hexid, lines = None, None, []
+    try:
+        if rank == 0:
+            child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            while time.time() < deadline:      # the first line is the id (or a failure)
+                line = child.stdout.readline()
+                if not line:
+                    break
+                lines.append(line.strip())
+                if line.startswith("ID "):
+                    hexid = line.split()[1]
+                    break
+        hexid = exchange_id(hexid)              # collective over the launcher's own transport; None = rank 0 has none
+        if hexid is None:
+            if child:
+                child.kill()
+            return {"ok": False, "seconds": time.time() - t0, "detail": "rank 0 produced no id: " + " | ".join(lines[-3:])}
+        if rank != 0:
+            child = subprocess.Popen(cmd + ["--id", hexid], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                     stderr=subprocess.STDOUT, text=True)
+        try:
+            out, _ = child.communicate(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            child.kill()
+            out, _ = child.communicate()
+            tail = " | ".join((lines + (out or "").strip().splitlines())[-3:])
+            return {"ok": False, "seconds": time.time() - t0, "detail": f"timed out after {timeout:.0f} s: {tail}"}
+        lines += (out or "").strip().splitlines()
+        ok = child.returncode == 0 and any(l.startswith("PREFLIGHT OK") for l in lines)
+        return {"ok": ok, "seconds": time.time() - t0, "detail": (lines[-1] if lines else f"exit code {child.returncode}")[:400]}
+    except Exception as e:                      # pragma: no cover - the pre-flight must never take the job down
+        if child and child.poll() is None:
+            child.kill()
+        return {"ok": False, "seconds": time.time() - t0, "detail": f"{type(e).__name__}: {e}"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--id", default=None)
+    ap.add_argument("--bytes", type=int, default=64 << 20)
+    ap.add_argument("--lib", default=None)
+    return _child(ap.parse_args())
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -123,6 +123,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sdpb_hip_host_syncs.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_host_syncs.restype = ctypes.c_long
+    L.sdpb_hip_progress.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
     L.sdpb_hip_plan_blocks.argtypes = [ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int, c_int_p]
     L.sdpb_hip_op_scalar.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 4 + [ctypes.c_size_t, size_p]
     L.sdpb_hip_op_int_syrk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
@@ -268,6 +269,17 @@ class SDPSolver:
     @property
     def host_syncs(self) -> int:
         return int(self.L.sdpb_hip_host_syncs(self.h))
+
+    def progress(self) -> dict:
+        """Lock-free progress record (sdpb_hip_progress): safe to call from a watchdog thread while another
+        thread is inside iterate() (ctypes releases the GIL during the call)."""
+        out = (ctypes.c_ulonglong * 8)()
+        self.L.sdpb_hip_progress(self.h, out)
+        kinds = {0: None, 1: "all-gather", 2: "all-reduce", 3: "broadcast"}
+        return {"iteration": int(out[0]), "host_syncs": int(out[1]), "collectives": int(out[2]),
+                "sequence_hash": f"{int(out[3]):016x}", "last_collective": kinds.get(int(out[4]), int(out[4])),
+                "last_bytes": int(out[5]), "last_root": int(out[6]) - 1 if out[6] else None,
+                "transport_async_error": int(out[7])}
 
     # -- SDP_Solver surface -------------------------------------------------------
     def block_owner(self, j: int) -> int:

@@ -206,6 +206,7 @@ inline unsigned long long wall_clock64()
   return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10ull;
 }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicMax(int *p, int v)
 {
   int old = __atomic_load_n(p, __ATOMIC_SEQ_CST);

@@ -10,6 +10,13 @@ data.  tests/test_gpu_parity.py::test_gpu_matches_oracle_fixture_at_full_size re
 
     python tests/golden/synthetic/make_synthetic_golden.py C4 2
     python tests/golden/synthetic/make_synthetic_golden.py C3 4
+    python tests/golden/synthetic/make_synthetic_golden.py C3 term            # until SDP_Solver::run stops
+    python tests/golden/synthetic/make_synthetic_golden.py C4 term 0.25 C4_x0.25_to_termination
+
+With `term` the oracle runs until its loop ends (run.cxx:380-467: a terminate reason from
+compute_feasible_and_termination.cxx or step.cxx:145-153) and the fixture also records
+`terminate_reason`, `terminated_in_iteration` (the iteration whose loop body stopped: it has no
+record, exactly like iterations.json) and the final `primalObjective`/`dualObjective`.
 """
 import json
 import os
@@ -23,7 +30,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     cfg = sys.argv[1]
-    iters = int(sys.argv[2])
+    to_term = sys.argv[2] == "term"
+    iters = 10 ** 6 if to_term else int(sys.argv[2])
     scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     from oracle.oracle import Oracle
     from sdpb_amd import synthetic
@@ -35,7 +43,8 @@ def main():
     print(f"{cfg}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total} p={c['precision']} threads={o.threads} "
           f"setup {time.time() - t0:.0f}s", flush=True)
     recs, secs = [], []
-    name = cfg if scale == 1.0 else f"{cfg}_x{scale}"
+    name = sys.argv[4] if len(sys.argv) > 4 else (cfg if scale == 1.0 else f"{cfg}_x{scale}")
+    final = {}
 
     def write():
         # rewritten after every iteration: a long run that is cut short keeps what it has
@@ -44,14 +53,22 @@ def main():
                "generator": "tests/golden/synthetic/make_synthetic_golden.py (oracle/sdpb_oracle.cpp)",
                "oracle_threads": o.threads, "oracle_seconds_per_iteration": [round(s, 1) for s in secs],
                "iterations": recs}
-        tmp = os.path.join(HERE, f".{name}.json.tmp")
+        out.update(final)
+        dest = os.environ.get("SDPB_FIXTURE_DIR", HERE)   # a long run may write elsewhere and be moved in when complete
+        tmp = os.path.join(dest, f".{name}.json.tmp")
         with open(tmp, "w") as f:
             json.dump(out, f, indent=1)
-        os.replace(tmp, os.path.join(HERE, f"{name}.json"))
+        os.replace(tmp, os.path.join(dest, f"{name}.json"))
 
     for it in range(iters):
         t = time.time()
-        assert not o.iterate(), o.terminate_reason
+        if o.iterate():
+            assert to_term, o.terminate_reason
+            final.update({"terminate_reason": o.terminate_reason, "terminated_in_iteration": it + 1,
+                          "primalObjective": o.scalar("primalObjective"), "dualObjective": o.scalar("dualObjective")})
+            print(f"terminated in iteration {it + 1}: {o.terminate_reason}", flush=True)
+            write()
+            break
         secs.append(time.time() - t)
         rec = o.scalars()
         rec["iteration"] = it + 1

@@ -82,8 +82,16 @@ def test_gpu_matches_oracle_fixture_at_full_size(fixture):
         bad, w = parity.compare_iteration(s.scalars(), rec, tol_bits=p // 2)
         worst = max(worst, w)
         assert not bad, f"{fixture} iteration {rec['iteration']}: {bad}"
+    if "terminate_reason" in fx:
+        # fixtures made with `term`: the oracle's loop ended in the NEXT iteration (run.cxx:380-467; that
+        # iteration has no record, as in iterations.json) — same iteration, same reason, same final objectives here
+        assert len(fx["iterations"]) + 1 == fx["terminated_in_iteration"]
+        assert s.iterate(), f"{fixture}: no termination in iteration {fx['terminated_in_iteration']}"
+        assert s.terminate_reason == fx["terminate_reason"]
+        for key in ("primalObjective", "dualObjective"):
+            assert parity.log2_rel(s.scalar(key), fx[key]) <= -(p // 2), key
     print(f"{fixture}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total}: {len(fx['iterations'])} iterations, "
-          f"worst log2 rel diff {worst:.1f}")
+          f"worst log2 rel diff {worst:.1f}" + (f", then '{fx['terminate_reason']}'" if "terminate_reason" in fx else ""))
     s.close()
 
 

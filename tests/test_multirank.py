@@ -30,3 +30,15 @@ def test_cholesky_Q_distributed_over_the_ranks(name, n_iter, world):
     for got, want in zip(results[0][2], iters):
         bad, _ = parity.compare_iteration(got, want)
         assert not bad, (want["iteration"], bad)
+
+
+def test_ranks_that_fall_out_of_step_fail_alike():
+    """The collective-sequence self-check (kernels.hpp: XW_SEQ_LO; include/sdpb_hip.h: sdpb_hip_progress): rank 1's
+    hash of the (kind, bytes, root) sequence is perturbed (SDPB_HIP_TEST_SEQ_FAULT=1 — the collectives themselves stay
+    matched, so nothing hangs); at the first synchronisation point BOTH ranks must raise the same code-3 error instead
+    of iterating on."""
+    results = run_ranks(2, "1d-constraints", 2, timeout=600, gpu=False, env={"SDPB_HIP_TEST_SEQ_FAULT": "1"})
+    errs = [r[2][-1].get("error") for r in results]
+    assert errs[0] is not None and errs[0] == errs[1], errs
+    assert errs[0][0] == 3 and "collective sequence mismatch: rank 1 and rank 0" in errs[0][1], errs[0]
+    assert all(len(r[2]) == 1 for r in results)          # raised at synchronisation point 1 of iteration 1

@@ -42,7 +42,7 @@ def _load(case):
     return sdp, meta["precision"], meta["params"], None, iters
 
 
-def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=None):
+def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=None, transport="callbacks"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.environ.update(env or {})
@@ -54,35 +54,50 @@ def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=No
     try:
         from sdpb_amd.distributed import make_collectives
         from sdpb_amd.solver import SDPSolver
+        # transport "rccl": one rank per GPU and the library's own communicator (needs `world` devices);
+        # "callbacks": the ranks share device 0 and exchange through host-staged gloo
+        devno = rank if transport == "rccl" else 0
         if gpu:
-            torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0) if gpu else torch.device("cpu")
+            torch.cuda.set_device(devno)
+        dev = torch.device("cuda", devno) if gpu else torch.device("cpu")
         sdp, precision, params, src, _ = _load(case)
         # gpu=False: the CPU twin of this test (tests/test_multirank.py) on the emulation build
-        s = SDPSolver(sdp, precision, params, device=0, rank=rank, world_size=world,
+        s = SDPSolver(sdp, precision, params, device=devno, rank=rank, world_size=world,
                       lib_path=libs.product_lib() if gpu else libs.emu_lib(panel=emu_panel), upload_all_blocks=False,
                       block_source=src)
-        s.set_collectives(*make_collectives(dev))
+        if transport == "rccl":
+            box = [s.rccl_unique_id().hex() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            s.rccl_init(bytes.fromhex(box[0]))
+        else:
+            s.set_collectives(*make_collectives(dev))
         owners = [s.block_owner(j) for j in range(sdp.J)]
+        from sdpb_amd.solver import SDPBError
         recs = []
         for _ in range(n_iter):
-            if s.iterate():
-                recs.append({"terminated": s.terminate_reason})
+            try:
+                if s.iterate():
+                    recs.append({"terminated": s.terminate_reason})
+                    break
+            except SDPBError as e:   # the ranks must fail alike: the error is part of the record that is compared
+                recs.append({"error": (e.code, str(e))})
                 break
             recs.append(s.scalars())
         t = s.timers()
-        q.put((rank, owners, recs, {k: v for k, v in t.items() if k.startswith("comm.")}, s.comm_name))
+        comm = {k: v for k, v in t.items() if k.startswith("comm.")}
+        comm["progress"] = s.progress()
+        q.put((rank, owners, recs, comm, s.comm_name))
         s.close()
     finally:
         dist.destroy_process_group()
 
 
-def run_ranks(world, case, n_iter, timeout=900, gpu=True, env=None, emu_panel=None):
+def run_ranks(world, case, n_iter, timeout=900, gpu=True, env=None, emu_panel=None, transport="callbacks"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, n_iter, q, gpu, env, emu_panel)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, n_iter, q, gpu, env, emu_panel, transport)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=timeout) for _ in procs)
@@ -92,17 +107,24 @@ def run_ranks(world, case, n_iter, timeout=900, gpu=True, env=None, emu_panel=No
     return results
 
 
-def check_ranks(results, world, J, cholesky_Q="replicated", panels=None):
+def check_ranks(results, world, J, cholesky_Q="replicated", panels=None, transport="callbacks"):
     owners0 = results[0][1]
     for rank, owners, recs, comm, name in results:
         assert owners == owners0                       # the same plan on every rank
-        assert name == "callbacks"
+        assert name == transport
+        if transport == "rccl":
+            assert comm["comm.ranks"] == world         # ncclCommCount
         assert comm["comm.world"] == world
         assert comm["comm.owned_blocks"] == owners0.count(rank) and 0 < comm["comm.owned_blocks"] < J
         # per iteration: one Q' all-reduce, three result-block all-gathers + three N-vector all-gathers
         assert comm["comm.allreduce_calls"] >= len(recs) and comm["comm.allgather_calls"] >= 6 * len(recs)
         assert recs == results[0][2], f"rank {rank} diverged from rank 0"   # lock-step, bit for bit
         assert comm["comm.cholesky_Q"] == cholesky_Q
+        # the collective-sequence self-check: same number of collectives, same (kind, bytes, root) hash everywhere
+        pr, pr0 = comm["progress"], results[0][3]["progress"]
+        assert pr["collectives"] == pr0["collectives"] == comm["comm.collectives"] > 0
+        assert pr["sequence_hash"] == pr0["sequence_hash"] == comm["comm.sequence_hash"].rjust(16, "0")
+        assert pr["iteration"] == len(recs) and pr["host_syncs"] >= 3 * (len(recs) - 1) + 1 and pr["transport_async_error"] == 0
         if cholesky_Q == "distributed":   # one broadcast per column panel of Q and iteration
             assert comm["comm.broadcast_calls"] == panels * len(recs), (comm["comm.broadcast_calls"], panels, len(recs))
     assert sorted(set(owners0)) == list(range(world)) and len(owners0) == J  # a partition, nobody idle
@@ -160,6 +182,74 @@ def test_ranks_sharing_one_gpu_match_the_oracle_at_bench_shape(world):
         bad, worst = parity.compare_iteration(results[0][2][it], o.scalars(), tol_bits=precision // 2)
         assert not bad, (it + 1, bad)
     o.close()
+
+
+def _gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+# ---- the in-library RCCL communicator with one rank PER GPU: runs wherever the box has >= 2 devices (the 1-GPU test
+# ---- box skips; RCCL refuses two ranks on one device and the box's compute partitions cannot be changed from inside
+# ---- the container: profiles/r04_partition_probe.txt)
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case,n_iter,dist_cholq", [(2, "dfibo", 3, False), (2, "C4x0.25", 3, False), (2, "C4x0.25", 3, True),
+                                                          (4, "C4x0.25", 3, False), (4, "C4x0.25", 3, True), (8, "C4x0.25", 2, True)])
+def test_in_library_rccl_with_one_rank_per_gpu(world, case, n_iter, dist_cholq):
+    """restore_and_reduce.cxx:137-212 and the distributed El::Cholesky of initialize_schur_complement_solver.cxx:95-103
+    on the production transport: ncclAllReduce / ncclAllGather / ncclBroadcast inside the library, ranks bit-identical,
+    golden trace (dfibo) or live oracle (C4 x0.25)."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_gpus()}")
+    sdp, precision, params, src, iters = _load(case)
+    env = {"SDPB_HIP_DIST_CHOLQ": "1"} if dist_cholq else None
+    results = run_ranks(world, case, n_iter, env=env, transport="rccl")
+    check_ranks(results, world, sdp.J, "distributed" if dist_cholq else "replicated", -(-sdp.N // 32), transport="rccl")
+    if iters is not None:
+        for got, want in zip(results[0][2], iters):
+            bad, _ = parity.compare_iteration(got, want)
+            assert not bad, (want["iteration"], bad)
+        return
+    from oracle.oracle import Oracle
+    o = Oracle(sdp, precision, params, param_prec=0, block_source=src)
+    for it in range(n_iter):
+        assert not o.iterate()
+        bad, _ = parity.compare_iteration(results[0][2][it], o.scalars(), tol_bits=precision // 2)
+        assert not bad, (it + 1, bad)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_rccl_preflight_child_process():
+    """sdpb_amd/rccl_preflight.py (what bench.py runs before it trusts the in-library exchange): with one rank on the
+    one GPU the test box has, and with one rank per GPU wherever there are more."""
+    from sdpb_amd import rccl_preflight
+    rec = rccl_preflight.run(0, 1, 0, lambda h: h, timeout=300, nbytes=1 << 20)
+    assert rec["ok"], rec
+    n = _gpus()
+    if n >= 2:
+        import threading
+        world, box, recs = min(n, 8), {}, [None] * min(n, 8)
+        have = threading.Event()
+
+        def xid(r):
+            def f(h):
+                if r == 0:
+                    box["id"] = h
+                    have.set()
+                have.wait(300)
+                return box.get("id")
+            return f
+
+        def one(r):
+            recs[r] = rccl_preflight.run(r, world, r, xid(r), timeout=300, nbytes=16 << 20)
+        ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert all(r and r["ok"] for r in recs), recs
 
 
 if __name__ == "__main__":

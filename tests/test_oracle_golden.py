@@ -65,3 +65,30 @@ def test_oracle_is_bit_identical_for_any_thread_count():
         traces.append(t)
         o.close()
     assert traces[0] == traces[1] == traces[2]
+
+
+@pytest.mark.parametrize("precision,rows,cols", [(128, 40, 7), (512, 37, 9), (1024, 300, 5)])
+def test_reference_crt_blas_algorithm_matches_exact_integers(precision, rows, cols):
+    """oracle/bigint_syrk_blas.py restates the reference's OWN algorithm for the dominant stage (primes as in
+    Fmpz_Comb.cxx:23-73, centred fp64 residues, one dsyrk per prime, CRT: bigint_syrk_blas.cxx:183-302); bench.py
+    times it as the CPU baseline of that stage.  Exact against plain Python integers and against the GMP port."""
+    import random
+    from oracle import bigint_syrk_blas as ref
+    from oracle.oracle import Oracle
+    rng = random.Random(precision + rows)
+    vals = [rng.randrange(-(2 ** precision) + 1, 2 ** precision) for _ in range(rows * cols)]
+    vals[0], vals[1], vals[2] = 2 ** precision - 1, -(2 ** precision) + 1, 0
+    got = ref.int_syrk(vals, rows, cols, precision)
+    sdp, _, _, _ = parity.load_case("1d")
+    o = Oracle(sdp, precision)
+    port = o.int_syrk(rows, cols, vals)          # upper triangle, column-major: entry (i <= j) at i + j * cols
+    o.close()
+    for i in range(cols):
+        for j in range(i + 1):
+            want = sum(vals[r + i * rows] * vals[r + j * rows] for r in range(rows))
+            assert got[i][j] == want, (i, j)
+            assert port[j + i * cols] == want, (i, j)
+    primes = ref.calculate_primes(ref.output_bits(precision, precision, rows), rows)
+    assert primes == sorted(primes, reverse=True) and primes[0] < 1664544 and (primes[0] // 2) ** 2 * rows < 2 ** 53
+    # the shape the bench quotes: k = 40 000 rows at --precision 512 -> 53 primes of ~19.9 bits
+    assert len(ref.calculate_primes(ref.output_bits(512, 512, 40000), 40000)) == 53

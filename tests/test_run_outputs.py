@@ -64,8 +64,10 @@ def _check_outputs(name, out_dir, tol_bits=99):
 
 def _argv(name, out_dir, lib=None):
     _, meta, _, _ = parity.load_case(name)
-    argv = ["-s", os.path.join(parity.GOLDEN, name, "sdp"), "-o", out_dir, "--precision", str(meta["precision"]),
-            "--verbosity", "0", "--writeSolution", "x,y,z,X,Y"]
+    # -c: the checkpoint directory (where the timing run writes block_timings) next to the OUTPUT, never next to the
+    # fixture: sdpb's default <sdpDir>.ck would write into tests/golden/ and later runs would plan on a stale file
+    argv = ["-s", os.path.join(parity.GOLDEN, name, "sdp"), "-o", out_dir, "-c", out_dir.rstrip("/") + ".ck",
+            "--precision", str(meta["precision"]), "--verbosity", "0", "--writeSolution", "x,y,z,X,Y"]
     for k, v in meta["params"].items():   # the flags end-to-end.test.cxx passes, verbatim
         if k in parity.FLAG_KEYS and k != "maxIterations":
             if int(v):

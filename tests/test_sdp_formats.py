@@ -122,7 +122,7 @@ def test_driver_solves_a_zipped_binary_sdp_like_the_json_directory(tmp_path):
     outs = []
     for src in (os.path.join(parity.GOLDEN, name, "sdp"), z):
         out = tmp_path / ("out_" + str(len(outs)))
-        argv = ["-s", src, "-o", str(out), "--precision", str(meta["precision"]), "--lib", libs.emu_lib(),
+        argv = ["-s", src, "-o", str(out), "-c", str(out) + ".ck", "--precision", str(meta["precision"]), "--lib", libs.emu_lib(),
                 "--maxIterations", "6", "--verbosity", "0"]
         for k, v in meta["params"].items():
             if k != "maxIterations":
