@@ -384,6 +384,10 @@ def main():
     ap.add_argument("--exchange", default=os.environ.get("SDPB_BENCH_EXCHANGE", "auto"), choices=["auto", "rccl", "callbacks"],
                     help="world > 1: auto = the in-library RCCL communicator if its pre-flight passes, else torch.distributed "
                          "(backend nccl = RCCL) behind the C-ABI callbacks; rccl / callbacks force one")
+    ap.add_argument("--share-one-gpu", action="store_true", default=os.environ.get("SDPB_BENCH_SHARE_ONE_GPU") == "1",
+                    help="all ranks of --gpus N use device 0 and RCCL connects them over its socket transport "
+                         "(sdpb_amd/rccl_preflight.one_gpu_env): executes the multi-rank exchange on a 1-GPU box; the "
+                         "line is flagged NOT_A_SCALING_MEASUREMENT")
     ap.add_argument("--watchdog", type=float, default=float(os.environ.get("SDPB_BENCH_WATCHDOG_S", "300")),
                     help="world > 1: seconds without progress after which a rank prints a WATCHDOG line and exits 124 (0 = off)")
     ap.add_argument("--lib", default=None, help="developer aid: another gfx950 build of libsdpb_hip.so (A/B of kernel variants)")
@@ -403,6 +407,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share = bool(args.share_one_gpu and world > 1)
+    if share:
+        from sdpb_amd import rccl_preflight
+        os.environ.update(rccl_preflight.one_gpu_env(rank))
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     sim = args.simulate_world if world == 1 else 0
@@ -451,7 +460,7 @@ def main():
             from sdpb_amd import rccl_preflight
             dog.enter("rccl pre-flight (child processes)")
             pre = rccl_preflight.run(rank, world, local_rank, exchange_id, timeout=min(120.0, max(30.0, args.watchdog / 2 or 120.0)),
-                                     lib_path=args.lib)
+                                     lib_path=args.lib)   # the child inherits os.environ (one_gpu_env when the ranks share a GPU)
             use_rccl = all_ok(pre["ok"])
         if use_rccl:
             dog.enter("sdpb_hip_rccl_init")
@@ -620,6 +629,9 @@ def main():
             "rccl_ranks": (min(int(r["ranks"]) for r in per_rank) if all(r["transport"] == "rccl" for r in per_rank)
                            else (1 if world == 1 else 0)),
             "exchange_setup": exchange_record,
+            **({"ranks_share_one_gpu": "NOT_A_SCALING_MEASUREMENT: all ranks ran on device 0 and RCCL used its socket "
+                                       "transport over loopback; this line shows the multi-rank exchange executing, "
+                                       "nothing about xGMI or speed-up"} if share else {}),
             # every rank hashes the (kind, bytes, root) of each collective it enqueues; the hashes are compared on the
             # device at every synchronisation point (a mismatch ends all ranks with the same error) and reported here
             "collective_sequence": {"hash": hashes[0], "identical_on_all_ranks": len(set(hashes)) == 1,

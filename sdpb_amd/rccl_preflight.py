@@ -25,6 +25,17 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def one_gpu_env(rank: int) -> dict:
+    """Environment that lets several RCCL ranks share ONE GPU (test boxes with a single device).
+    RCCL refuses two ranks whose (host hash, PCI bus id) coincide ("Duplicate GPU detected").  NCCL_HOSTID replaces
+    the host hash: with one id per rank the ranks look like one-GPU hosts, the check passes and RCCL connects them with
+    its net/Socket transport over loopback (profiles/r04_rccl_two_ranks_one_gpu.log).  Not xGMI -- no bandwidth claim
+    follows from such a run -- but every ncclAllReduce / ncclAllGather / ncclBroadcast of csrc/rccl_comm.hpp executes
+    with world > 1 on the device.  Must be in os.environ before the communicator is created."""
+    return {"NCCL_HOSTID": f"sdpb-rank-{rank}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_NET": "Socket", "NCCL_IB_DISABLE": "1",
+            "NCCL_P2P_DISABLE": "1", "NCCL_SHM_DISABLE": "1"}
+
+
 def _child(args) -> int:
     from sdpb_amd.solver import load_library
     import torch  # the library binds to torch's HIP runtime / RCCL (solver.load_library imports it first as well)
@@ -53,11 +64,12 @@ def _child(args) -> int:
 
 
 def run(rank: int, world: int, device: int, exchange_id, timeout: float = 120.0, nbytes: int = 64 << 20,
-        lib_path: str | None = None) -> dict:
+        lib_path: str | None = None, extra_env: dict | None = None) -> dict:
     """One rank's part of the pre-flight: start the child, move rank 0's id through `exchange_id`, wait.
     Returns {"ok": bool, "seconds": s, "detail": str}.  Never raises for a failing or hanging child."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):   # the child is not a torchrun worker
         env.pop(k, None)
     cmd = [sys.executable, "-m", "sdpb_amd.rccl_preflight", "--rank", str(rank), "--world", str(world),

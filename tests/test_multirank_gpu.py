@@ -42,10 +42,17 @@ def _load(case):
     return sdp, meta["precision"], meta["params"], None, iters
 
 
+def rccl_one_gpu_env(rank):
+    from sdpb_amd.rccl_preflight import one_gpu_env
+    return one_gpu_env(rank)
+
+
 def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=None, transport="callbacks"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.environ.update(env or {})
+    if transport == "rccl-one-gpu":
+        os.environ.update(rccl_one_gpu_env(rank))
     sys.path.insert(0, libs.ROOT)
     import torch
     import torch.distributed as dist
@@ -56,7 +63,8 @@ def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=No
         from sdpb_amd.solver import SDPSolver
         # transport "rccl": one rank per GPU and the library's own communicator (needs `world` devices);
         # "callbacks": the ranks share device 0 and exchange through host-staged gloo
-        devno = rank if transport == "rccl" else 0
+        rccl, transport = transport.startswith("rccl"), "rccl" if transport.startswith("rccl") else transport
+        devno = rank if rccl and os.environ.get("NCCL_HOSTID") is None else 0
         if gpu:
             torch.cuda.set_device(devno)
         dev = torch.device("cuda", devno) if gpu else torch.device("cpu")
@@ -111,6 +119,7 @@ def check_ranks(results, world, J, cholesky_Q="replicated", panels=None, transpo
     owners0 = results[0][1]
     for rank, owners, recs, comm, name in results:
         assert owners == owners0                       # the same plan on every rank
+        transport = "rccl" if transport.startswith("rccl") else transport
         assert name == transport
         if transport == "rccl":
             assert comm["comm.ranks"] == world         # ncclCommCount
@@ -192,21 +201,24 @@ def _gpus():
         return 0
 
 
-# ---- the in-library RCCL communicator with one rank PER GPU: runs wherever the box has >= 2 devices (the 1-GPU test
-# ---- box skips; RCCL refuses two ranks on one device and the box's compute partitions cannot be changed from inside
-# ---- the container: profiles/r04_partition_probe.txt)
+# ---- the in-library RCCL communicator: one rank PER GPU wherever the box has the devices; on the 1-GPU test box the
+# ---- ranks share device 0 (compute partitions cannot be changed from inside the container,
+# ---- profiles/r04_partition_probe.txt) and RCCL is made to accept them through NCCL_HOSTID (rccl_preflight.one_gpu_env)
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,case,n_iter,dist_cholq", [(2, "dfibo", 3, False), (2, "C4x0.25", 3, False), (2, "C4x0.25", 3, True),
                                                           (4, "C4x0.25", 3, False), (4, "C4x0.25", 3, True), (8, "C4x0.25", 2, True)])
-def test_in_library_rccl_with_one_rank_per_gpu(world, case, n_iter, dist_cholq):
+def test_in_library_rccl_with_more_than_one_rank(world, case, n_iter, dist_cholq):
     """restore_and_reduce.cxx:137-212 and the distributed El::Cholesky of initialize_schur_complement_solver.cxx:95-103
     on the production transport: ncclAllReduce / ncclAllGather / ncclBroadcast inside the library, ranks bit-identical,
     golden trace (dfibo) or live oracle (C4 x0.25)."""
-    if _gpus() < world:
-        pytest.skip(f"needs {world} GPUs, this box has {_gpus()}")
+    if _gpus() < 1:
+        pytest.skip("needs a GPU")
+    # one rank per GPU where the box has them; otherwise the ranks share device 0 and RCCL connects them over its
+    # socket transport (rccl_one_gpu_env)
+    transport = "rccl" if _gpus() >= world else "rccl-one-gpu"
     sdp, precision, params, src, iters = _load(case)
     env = {"SDPB_HIP_DIST_CHOLQ": "1"} if dist_cholq else None
-    results = run_ranks(world, case, n_iter, env=env, transport="rccl")
+    results = run_ranks(world, case, n_iter, env=env, transport=transport)
     check_ranks(results, world, sdp.J, "distributed" if dist_cholq else "replicated", -(-sdp.N // 32), transport="rccl")
     if iters is not None:
         for got, want in zip(results[0][2], iters):
@@ -230,9 +242,11 @@ def test_rccl_preflight_child_process():
     rec = rccl_preflight.run(0, 1, 0, lambda h: h, timeout=300, nbytes=1 << 20)
     assert rec["ok"], rec
     n = _gpus()
-    if n >= 2:
+    share = n < 2          # the ranks share device 0 (rccl_preflight.one_gpu_env)
+    if True:
         import threading
-        world, box, recs = min(n, 8), {}, [None] * min(n, 8)
+        world = 2 if share else min(n, 8)
+        box, recs = {}, [None] * world
         have = threading.Event()
 
         def xid(r):
@@ -245,7 +259,8 @@ def test_rccl_preflight_child_process():
             return f
 
         def one(r):
-            recs[r] = rccl_preflight.run(r, world, r, xid(r), timeout=300, nbytes=16 << 20)
+            recs[r] = rccl_preflight.run(r, world, 0 if share else r, xid(r), timeout=300, nbytes=16 << 20,
+                                         extra_env=rccl_preflight.one_gpu_env(r) if share else None)
         ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
         [t.start() for t in ts]
         [t.join() for t in ts]
@@ -254,8 +269,10 @@ def test_rccl_preflight_child_process():
 
 if __name__ == "__main__":
     world, case, n_iter = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
-    res = run_ranks(world, case, n_iter)
+    transport = sys.argv[4] if len(sys.argv) > 4 else "callbacks"     # callbacks | rccl | rccl-one-gpu
+    dist_q = os.environ.get("SDPB_HIP_DIST_CHOLQ") == "1"
+    res = run_ranks(world, case, n_iter, transport=transport)
     sdp = _load(case)[0]
-    check_ranks(res, world, sdp.J)
+    check_ranks(res, world, sdp.J, "distributed" if dist_q else "replicated", -(-sdp.N // 32), transport=transport)
     for rank, owners, recs, comm, name in res:
         print(f"rank {rank}: {comm} P-obj={recs[-1].get('P-obj', '')[:40]}")
