@@ -263,10 +263,10 @@ def dry_run(args, lib, rank, world):
         assert len(set(objs)) == 1, "ranks diverged"
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "interior-point iterations/sec at --precision 512", "value": None, "unit": "iterations/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "DRY_RUN_NOT_A_MEASUREMENT": True,
-                          "config": {"workload": f"{args.workload} x{args.scale}: J={sdp.J}, N={sdp.N}", "exchange": solver.comm_name},
-                          "P-obj": obj}), flush=True)
+        emit({"metric": "interior-point iterations/sec at --precision 512", "value": None, "unit": "iterations/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "DRY_RUN_NOT_A_MEASUREMENT": True,
+              "config": {"workload": f"{args.workload} x{args.scale}: J={sdp.J}, N={sdp.N}", "exchange": solver.comm_name},
+              "P-obj": obj})
     solver.close()
     if world > 1:
         dist.destroy_process_group()
@@ -307,13 +307,34 @@ class Watchdog:
             if key != self.last:
                 self.last, self.t_last = key, time.time()
             elif self.armed and time.time() - self.t_last > self.limit:
-                print(json.dumps({"metric": "interior-point iterations/sec", "value": None, "WATCHDOG": {
+                emit({"metric": "interior-point iterations/sec", "value": None, "WATCHDOG": {
                     "rank": self.rank, "world": self.world, "phase": self.phase, "no_progress_for_s": round(time.time() - self.t_last, 1),
                     "progress": rec, "note": "no iteration, synchronisation point or collective completed on this rank within the "
                                              "limit: a collective is waiting for a rank that never enqueued its part (compare "
-                                             "`collectives` and `sequence_hash` across the ranks' lines), or the transport hangs"}}),
-                      flush=True)
+                                             "`collectives` and `sequence_hash` across the ranks' lines), or the transport hangs"}})
                 os._exit(124)
+
+
+_JSON_FD = None
+
+
+def claim_stdout():
+    """Keep stdout for the ONE JSON line: everything else that writes to fd 1 in this process and its children (RCCL's
+    version banner, gloo's connection chatter, rocm-smi warnings) is sent to stderr from here on."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(record):
+    line = (json.dumps(record) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
 
 
 def load_workload(args):
@@ -404,6 +425,7 @@ def main():
     from sdpb_amd import workmodel
     from sdpb_amd.solver import SDPSolver
 
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -515,8 +537,8 @@ def main():
         gate = parity_gate(solver, args.workload, args.scale, precision)
     if gate and gate["passed"] is False:
         if rank == 0:
-            print(json.dumps({"metric": f"interior-point iterations/sec at --precision {precision}", "value": None,
-                              "PARITY_GATE_FAILED": True, "parity_gate": gate}), flush=True)
+            emit({"metric": f"interior-point iterations/sec at --precision {precision}", "value": None,
+                  "PARITY_GATE_FAILED": True, "parity_gate": gate})
         raise SystemExit("bench.py: the device iteration does not reproduce the oracle fixture; no value reported")
     solver.reset()
 
@@ -667,7 +689,7 @@ def main():
             out["SIMULATED_WORLD_NOT_A_MEASUREMENT"] = sim
         if world == 1 and not args.no_cpu_baseline and not golden:
             out["cpu_baseline"] = cpu_baseline(args.workload, precision, full=args.cpu_full)
-        print(json.dumps(out), flush=True)
+        emit(out)
     solver.close()
     if world > 1:
         dist.destroy_process_group()
