@@ -3406,12 +3406,12 @@ constexpr int TRI_T = SDPB_TRI_T;
 // (A two-level exact sum through a limb-major image, as in k_gemv_n, was measured here and is slower:
 // 4.74 instead of 4.61 ms per launch; every lane needs the result, and the kernel is bound by the
 // wavefront-instructions it issues, not by the depth of this tree.)
-template <int NL> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
+template <int NL, int T> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
 {
   const int t = threadIdx.x;
   sm[t] = v;
   __syncthreads();
-  for(int s = TRI_T / 2; s > 0; s >>= 1)
+  for(int s = T / 2; s > 0; s >>= 1)
     {
       if(t < s)
         sm[t] = mw::add(sm[t], sm[t + s]);
@@ -3421,7 +3421,10 @@ template <int NL> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
   __syncthreads();
   return r;
 }
-template <int NL> __global__ void __launch_bounds__(TRI_T, SDPB_TRI_WAVES) k_tridiag(Batch A, Batch D, Batch E)
+// T lanes per matrix: TRI_T where the matrices outnumber the workgroup slots of the chip (one rank, C4), 2 TRI_T / 4 TRI_T
+// where a rank owns so few that every matrix is resident anyway and the launch lasts as long as the Householder chain
+// of the largest one (a rank of an 8-GPU job: step lengths are then a chain that does not divide by the rank count).
+template <int NL, int T> __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TRI_WAVES : 1024 / T) k_tridiag(Batch A, Batch D, Batch E)
 {
   const int q = blockIdx.x;
   const MatDesc d = A.d[q];
@@ -3429,7 +3432,7 @@ template <int NL> __global__ void __launch_bounds__(TRI_T, SDPB_TRI_WAVES) k_tri
   const int n = d.rows, t = threadIdx.x;
   if(n == 0)
     return;
-  __shared__ Mw<NL> sm[TRI_T];
+  __shared__ Mw<NL> sm[T];
   __shared__ Mw<NL> s_hinv;
   for(int i = n - 1; i >= 1; --i)
     {
@@ -3441,12 +3444,12 @@ template <int NL> __global__ void __launch_bounds__(TRI_T, SDPB_TRI_WAVES) k_tri
           continue;
         }
       Acc<NL> hp = mw::acc_zero<NL>();
-      for(int k = t; k <= l; k += TRI_T)
+      for(int k = t; k <= l; k += T)
         {
           const Mw<NL> a = mat_ld<NL>(A, d, i, k);
           mw::acc_fma(hp, a, a);
         }
-      const Mw<NL> h0 = tri_reduce_sum<NL>(mw::acc_result(hp), sm);
+      const Mw<NL> h0 = tri_reduce_sum<NL, T>(mw::acc_result(hp), sm);
       if(mw::is_zero(h0))
         {
           if(t == 0)
@@ -3468,9 +3471,9 @@ template <int NL> __global__ void __launch_bounds__(TRI_T, SDPB_TRI_WAVES) k_tri
       const Mw<NL> hinv = s_hinv;
       // e[j] = (A_sub u)_j / h with teams of G lanes per row j
       const int w = l + 1;
-      int G = TRI_T / w;
+      int G = T / w;
       G = G < 1 ? 1 : (G > 8 ? 8 : G);
-      const int teams = TRI_T / G, g = t % G;
+      const int teams = T / G, g = t % G;
       Mw<NL> fpart = mw::zero<NL>();
       for(int j0 = 0; j0 < w; j0 += teams)
         {
@@ -3495,14 +3498,14 @@ template <int NL> __global__ void __launch_bounds__(TRI_T, SDPB_TRI_WAVES) k_tri
             }
           __syncthreads();
         }
-      const Mw<NL> f = tri_reduce_sum<NL>(fpart, sm);
+      const Mw<NL> f = tri_reduce_sum<NL, T>(fpart, sm);
       const Mw<NL> hh = mw::mul_2exp(mw::mul(f, hinv), -1);
-      for(int j = t; j < w; j += TRI_T)
+      for(int j = t; j < w; j += T)
         mw::store<NL>(E.p, oe + j, mw::sub(mw::load<NL>(E.p, oe + j), mw::mul(hh, mat_ld<NL>(A, d, i, j))));
       __syncthreads();
       // rank-2 update of the leading w x w lower triangle (packed index -> (j,k), k <= j)
       const int cnt = w * (w + 1) / 2;
-      for(int idx = t; idx < cnt; idx += TRI_T)
+      for(int idx = t; idx < cnt; idx += T)
         {
           int j = 0;
           while((j + 1) * (j + 2) / 2 <= idx)
@@ -3517,7 +3520,7 @@ template <int NL> __global__ void __launch_bounds__(TRI_T, SDPB_TRI_WAVES) k_tri
       __syncthreads();
     }
   __syncthreads();
-  for(int i = t; i < n; i += TRI_T)
+  for(int i = t; i < n; i += T)
     mw::store<NL>(D.p, od + i, mat_ld<NL>(A, d, i, i));
 }
 

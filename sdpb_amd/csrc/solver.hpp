@@ -349,6 +349,7 @@ template <int NL> class Solver : public SolverBase
   // Q substitution with lane-parallel exact sums (k_qsolve_panel3, round 4); SDPB_HIP_QSOLVE_SUM_LANES=0 runs the
   // round-3 kernel (k_qsolve_panel2: 8 + 4 dependent aligned adds per sum) for A/B measurements
   bool qsolve_sum_lanes_ = true;
+  bool tridiag_wide_ = true; // SDPB_HIP_TRIDIAG_WIDE=0: TRI_T lanes per matrix whatever the rank owns (A/B)
   int seq_fault_rank_ = -1; // SDPB_HIP_TEST_SEQ_FAULT=r: rank r perturbs its hash (test of the mismatch path)
   void note_collective(unsigned kind, size_t bytes, int root)
   {
@@ -717,6 +718,8 @@ private:
       seq_fault_rank_ = std::atoi(e);
     if(const char *e = std::getenv("SDPB_HIP_QSOLVE_SUM_LANES"))
       qsolve_sum_lanes_ = std::atoi(e) != 0;
+    if(const char *e = std::getenv("SDPB_HIP_TRIDIAG_WIDE"))
+      tridiag_wide_ = std::atoi(e) != 0;
     // opt-in (round-3 advisor): the production transport of its panel messages, ncclBroadcast, has not yet
     // run with more than one rank on hardware; the replicated factorisation uses no collective at all
     dist_cholq_ = false;
@@ -1869,7 +1872,14 @@ private:
     trsm_rlt(psd(Lc), psd(Li), psd(W), max_n_, max_n_);
     launch(k_transpose<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(W));
     trsm_rlt(psd(Lc), psd(Li), psd(W), max_n_, max_n_);
-    launch(k_tridiag<NL>, dim3(2 * Jl_), dim3(TRI_T), stream_, psd(W), vecn(D), vecn(E));
+    // lanes per matrix by how many matrices this rank owns (kernels.hpp, k_tridiag): all of them resident -> wider teams
+    const int mats = 2 * Jl_, slots = num_cus_ * (2048 / 4 / TRI_T); // workgroups of TRI_T lanes resident at 2 waves / SIMD
+    if(TRI_T * 4 <= 1024 && mats * 4 <= slots && tridiag_wide_)
+      launch(k_tridiag<NL, TRI_T * 4>, dim3(mats), dim3(TRI_T * 4), stream_, psd(W), vecn(D), vecn(E));
+    else if(TRI_T * 2 <= 1024 && mats * 2 <= slots && tridiag_wide_)
+      launch(k_tridiag<NL, TRI_T * 2>, dim3(mats), dim3(TRI_T * 2), stream_, psd(W), vecn(D), vecn(E));
+    else
+      launch(k_tridiag<NL, TRI_T>, dim3(mats), dim3(TRI_T), stream_, psd(W), vecn(D), vecn(E));
     launch(k_tridiag_min<NL>, dim3(cdiv(2 * Jl_, EIG_T)), dim3(EIG_T), stream_, vecn(D), vecn(E), F.p, F.p + psd_rows_local_ + 1, lam.ptr());
   }
   // The primal and the dual step length are two independent latency-bound chains (Householder
