@@ -538,7 +538,9 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch
 // chunks of a tile are staged in limb-major LDS
 template <int NL>
 __device__ void chol_syrk_tile(const Batch &A, const MatDesc &d, int k0, int nb, int b0, int M, int ti, int tj, int cmin = 0, int cmax = 1 << 30);
-template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p, int tile0, unsigned long long *cyc)
+// [col_lo, col_hi): only the columns of the matrix inside this window are updated (the chased Cholesky(Q) applies a
+// panel to the columns that exist so far and to the others when they arrive; 0, INT_MAX = all)
+template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A, int p, int tile0, unsigned long long *cyc, int col_lo, int col_hi)
 {
   const int q = blockIdx.y;
   WgClock clk(cyc, q);
@@ -556,7 +558,11 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_down(Batch A
   while((ti + 1) * (ti + 2) / 2 <= tile)
     ++ti;
   const int tj = tile - ti * (ti + 1) / 2;
-  chol_syrk_tile<NL>(A, d, k0, nb, b0, M, ti, tj);
+  // the window in the trailing matrix's own column numbers; a tile that straddles an end is masked per element
+  const int c_lo = col_lo > b0 ? col_lo - b0 : 0, c_hi = col_hi - b0 < M ? col_hi - b0 : M;
+  if(16 * tj + 16 <= c_lo || 16 * tj >= c_hi)
+    return;
+  chol_syrk_tile<NL>(A, d, k0, nb, b0, M, ti, tj, c_lo, c_hi);
 }
 // The same update restricted to the column panels q = q0, q0 + qstride, ... (count of them) of
 // the single matrix A.d[0]: the 1-D block-cyclic Cholesky(Q) over ranks updates only the panels a
@@ -2340,7 +2346,9 @@ __global__ void __launch_bounds__(WG) k_fx_colsum_final(const uint32_t *partial,
 
 // Lower-triangle 16x16 tiles of an N x N output, enumerated super-block by super-block
 // (8x8 tiles) so that consecutive entries share operand panels.
-inline std::vector<uint32_t> syrk_tile_order(int N)
+// split_tile > 0: the tiles of the columns left of tile column `split_tile` come first (super-block order inside
+// each group), *count_left = how many they are -- the two launches of the chunked Q' take the two halves of the list
+inline std::vector<uint32_t> syrk_tile_order(int N, int split_tile = 0, int *count_left = nullptr)
 {
   int SB = 8;
   if(const char *env = std::getenv("SDPB_HIP_SYRK_SB")) // tuning knob: super-block edge in tiles
@@ -2353,6 +2361,14 @@ inline std::vector<uint32_t> syrk_tile_order(int N)
         for(int tj = bj * SB; tj < std::min(tiles, (bj + 1) * SB); ++tj)
           if(tj <= ti)
             out.push_back((uint32_t)ti << 16 | (uint32_t)tj);
+  if(split_tile > 0)
+    {
+      std::stable_partition(out.begin(), out.end(), [=](uint32_t t) { return (int)(t & 0xffffu) < split_tile; });
+      if(count_left)
+        *count_left = (int)std::count_if(out.begin(), out.end(), [=](uint32_t t) { return (int)(t & 0xffffu) < split_tile; });
+    }
+  else if(count_left)
+    *count_left = (int)out.size();
   return out;
 }
 
@@ -2624,11 +2640,14 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 }
 
 // acc(i,j) = sum over the row splits of part[split](i,j)  (i >= j)
-template <int FX> __global__ void __launch_bounds__(WG) k_syrk_reduce(const uint32_t *part, int nsplit, uint32_t *acc, size_t acc_stride, int N)
+// [idx0, idx1): the entries (column-major, idx = i + j N) the launch covers -- whole columns of the output; the chunked
+// Q' (Solver::q_chase_) finishes, reduces and restores the left columns while the right ones are still being multiplied
+template <int FX>
+__global__ void __launch_bounds__(WG) k_syrk_reduce(const uint32_t *part, int nsplit, uint32_t *acc, size_t acc_stride, int N, size_t idx0, size_t idx1)
 {
   constexpr int W = 2 * FX + 2;
-  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= (size_t)N * N || (int)(idx % N) < (int)(idx / N))
+  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= idx1 || (int)(idx % N) < (int)(idx / N))
     return;
   uint64_t cy = 0;
 #pragma unroll
@@ -2865,11 +2884,11 @@ __global__ void __launch_bounds__(WG)
 // add the splits, remove the bias of the two signed evaluation points, interpolate, recombine.
 template <int FX>
 __global__ void __launch_bounds__(WG)
-  k_syrk4_finish(const uint32_t *part, int nsplit, const uint32_t *toomU, uint32_t *acc, size_t acc_stride, int N)
+  k_syrk4_finish(const uint32_t *part, int nsplit, const uint32_t *toomU, uint32_t *acc, size_t acc_stride, int N, size_t idx0, size_t idx1)
 {
   constexpr int M2 = FX / 4, A2 = 2 * M2 + 1, Z = 2 * M2 + 2, W = 2 * FX + 2, WB = 32 * M2 - 4;
-  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= (size_t)N * N)
+  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= idx1)
     return;
   const int i = (int)(idx % N), j = (int)(idx / N);
   if(i < j)
@@ -3257,11 +3276,11 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 //   acc(i,j) <- G(i,j) - C (S_i + S_j) + n C^2 = sum_r v_ri v_rj   (two's complement),
 // C = 2^FB, n = total number of rows, S behind the N x N block (k_fx_colsum).
 template <int FX>
-__global__ void __launch_bounds__(WG) k_syrk_unbias(uint32_t *acc, size_t acc_stride, int N, unsigned long long nrows_total)
+__global__ void __launch_bounds__(WG) k_syrk_unbias(uint32_t *acc, size_t acc_stride, int N, unsigned long long nrows_total, size_t idx0, size_t idx1)
 {
   constexpr int W = 2 * FX + 2, FB = fx_frac_bits<FX>();
-  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= (size_t)N * N)
+  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= idx1)
     return;
   const int i = (int)(idx % N), j = (int)(idx / N);
   if(i < j)
@@ -3295,11 +3314,11 @@ __global__ void __launch_bounds__(WG) k_syrk_unbias(uint32_t *acc, size_t acc_st
 // |Q'_ii - 1| < 2^(-16 FX).
 template <int NL, int FX>
 __global__ void __launch_bounds__(WG)
-  k_restore_Q(const uint32_t *acc, size_t acc_stride, int N, mw::CPtr norms, mw::Ptr Q, int *diag_fail)
+  k_restore_Q(const uint32_t *acc, size_t acc_stride, int N, mw::CPtr norms, mw::Ptr Q, int *diag_fail, size_t idx0, size_t idx1)
 {
   constexpr int W = 2 * FX + 2, FB = fx_frac_bits<FX>();
-  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= (size_t)N * N)
+  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= idx1)
     return;
   const int i = (int)(idx % N), j = (int)(idx / N);
   if(i < j)
@@ -3585,6 +3604,40 @@ __device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t
     }
 }
 
+// The Newton iteration on a ladder of widths: NL <- NL/2+1 <- ... down to about six limbs (192 bits: the fp64 bisection
+// delivers ~50 bits, two steps fill the first rung; narrower rungs would add their own rounding of D and E, which is
+// relative to the LARGEST entry, to a lambda_min that may be small against it).  Each rung ends below lambda_min of
+// its own rounded matrix; the next one steps 256 of the previous rung's ulps down and needs one step.  Cost in
+// limb^2 units at 576 bits: 2*36 + 100 + 324 instead of 3*100 + 324; at 832 bits 2*64 + 196 + 676 instead of
+// 4*196 + 676.
+template <int WL, int NL> struct TridiagLadder
+{
+  static constexpr int H = WL / 2 + 1;
+  static constexpr int MINW = NL / 2 + 1 < 6 ? NL / 2 + 1 : 6;
+  static __device__ void run(const Batch &D, const Batch &E, size_t od, size_t oe, int n, const Mw<NL> &start, Mw<WL> &x, double span, int emax)
+  {
+    if constexpr(H >= MINW && H < WL)
+      {
+        Mw<H> xs;
+        TridiagLadder<H, NL>::run(D, E, od, oe, n, start, xs, span, emax);
+        // step a few ulps of the narrower rung down so that this one starts from below
+        Mw<H> ulps = mw::abs(xs);
+        ulps.e -= 32 * H - 8;
+        xs = mw::sub(xs, ulps);
+        x = mw::widen<WL, H>(xs);
+        tridiag_newton<WL, NL>(D, E, od, oe, n, x, span, emax, 32 * H - 16);
+      }
+    else
+      {
+        if constexpr(WL < NL)
+          x = mw::narrow<WL, NL>(start);
+        else
+          x = start;
+        tridiag_newton<WL, NL>(D, E, od, oe, n, x, span, emax, 24);
+      }
+  }
+};
+
 // Stage 2: lambda_min of each tridiagonal matrix, one lane per matrix.  fa/fb2 are
 // fp64 work arrays laid out like D/E.  E is overwritten by its square.
 template <int NL>
@@ -3657,20 +3710,10 @@ __global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double 
     }
   // safely below lambda_min of the exact tridiagonal matrix
   Mw<NL> x = mw::mul_2exp(mw::from_double<NL>(blo - 1e-10 * span - 1e-300), emax);
-  // multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i; first at about
-  // half the limbs (quadratic convergence: the early steps need few bits), then one or
-  // two steps at full width
-  constexpr int WL = NL / 2 + 1;
-  Mw<WL> xs = mw::narrow<WL, NL>(x);
-  tridiag_newton<WL, NL>(D, E, od, oe, n, xs, span, emax, 24);
-  {
-    // step a few half-width ulps down so that the full-width stage starts from below
-    Mw<WL> ulps = mw::abs(xs);
-    ulps.e -= 32 * WL - 8;
-    xs = mw::sub(xs, ulps);
-  }
-  x = mw::widen<NL, WL>(xs);
-  tridiag_newton<NL, NL>(D, E, od, oe, n, x, span, emax, 32 * WL - 16);
+  // multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i, on a ladder of mantissa widths (TridiagLadder):
+  // quadratic convergence doubles the correct bits per step, so every step runs at the width it can fill
+  const Mw<NL> start = x;
+  TridiagLadder<NL, NL>::run(D, E, od, oe, n, start, x, span, emax);
   mw::store<NL>(lam, q, x);
 }
 
@@ -3961,27 +4004,34 @@ __global__ void __launch_bounds__(WG)
 // behind it carry information, so only those N(N+1)/2 + N entries per plane travel (half the
 // message).  Packed entry of (i, j): j N - j (j - 1) / 2 + (i - j); column sum i: N(N+1)/2 + i.
 // grid (cdiv(N, WG), N + 1): blockIdx.y = column j, j == N is the row of column sums.
+// Columns [c0, c1) only (a chunk of the chased Q'): the message holds their packed entries, then -- with_sums -- the N
+// column sums; grid (cdiv(N, WG), c1 - c0 + with_sums): blockIdx.y = c1 - c0 is the row of column sums.
+MW_HD size_t tri_packed_offset(int N, int j) { return (size_t)j * N - (size_t)j * (size_t)(j > 0 ? j - 1 : 0) / 2; }
 template <int UNUSED = 0>
-__global__ void __launch_bounds__(WG) k_widen_tri_u64(const uint32_t *acc, size_t acc_stride, int N, int planes, unsigned long long *out)
+__global__ void __launch_bounds__(WG)
+  k_widen_tri_u64(const uint32_t *acc, size_t acc_stride, int N, int planes, unsigned long long *out, int c0, int c1, int with_sums)
 {
-  const int i = blockIdx.x * WG + threadIdx.x, j = blockIdx.y;
-  if(i >= N || (j < N && i < j))
+  const int i = blockIdx.x * WG + threadIdx.x, j = c0 + (int)blockIdx.y;
+  const bool sums = j >= c1;
+  if(i >= N || (!sums && i < j))
     return;
-  const size_t T = (size_t)N * (N + 1) / 2 + N;
-  const size_t src = j < N ? (size_t)i + (size_t)j * N : (size_t)N * N + i;
-  const size_t dst = j < N ? (size_t)j * N - (size_t)j * (j - 1) / 2 + (size_t)(i - j) : (size_t)N * (N + 1) / 2 + i;
+  const size_t tri = tri_packed_offset(N, c1) - tri_packed_offset(N, c0), T = tri + (with_sums ? (size_t)N : 0);
+  const size_t src = !sums ? (size_t)i + (size_t)j * N : (size_t)N * N + i;
+  const size_t dst = !sums ? tri_packed_offset(N, j) - tri_packed_offset(N, c0) + (size_t)(i - j) : tri + i;
   for(int k = 0; k < planes; ++k)
     out[(size_t)k * T + dst] = acc[(size_t)k * acc_stride + src];
 }
 template <int UNUSED = 0>
-__global__ void __launch_bounds__(WG) k_narrow_tri_carry(const unsigned long long *in, int N, int planes, uint32_t *acc, size_t acc_stride)
+__global__ void __launch_bounds__(WG)
+  k_narrow_tri_carry(const unsigned long long *in, int N, int planes, uint32_t *acc, size_t acc_stride, int c0, int c1, int with_sums)
 {
-  const int i = blockIdx.x * WG + threadIdx.x, j = blockIdx.y;
-  if(i >= N || (j < N && i < j))
+  const int i = blockIdx.x * WG + threadIdx.x, j = c0 + (int)blockIdx.y;
+  const bool sums = j >= c1;
+  if(i >= N || (!sums && i < j))
     return;
-  const size_t T = (size_t)N * (N + 1) / 2 + N;
-  const size_t dst = j < N ? (size_t)i + (size_t)j * N : (size_t)N * N + i;
-  const size_t src = j < N ? (size_t)j * N - (size_t)j * (j - 1) / 2 + (size_t)(i - j) : (size_t)N * (N + 1) / 2 + i;
+  const size_t tri = tri_packed_offset(N, c1) - tri_packed_offset(N, c0), T = tri + (with_sums ? (size_t)N : 0);
+  const size_t dst = !sums ? (size_t)i + (size_t)j * N : (size_t)N * N + i;
+  const size_t src = !sums ? tri_packed_offset(N, j) - tri_packed_offset(N, c0) + (size_t)(i - j) : tri + i;
   unsigned long long carry = 0;
   for(int k = 0; k < planes; ++k)
     {

@@ -327,6 +327,13 @@ template <int NL> class Solver : public SolverBase
   // instead of replicated.  Opt-in with SDPB_HIP_DIST_CHOLQ=1 (worthwhile from N ~ 1536 up, where the N^3/3
   // trailing updates outweigh the per-panel broadcasts: C5-class); replicated otherwise.
   bool dist_cholq_ = false;
+  // Q' in two column chunks, Cholesky(Q) chasing it (initialize_schur_complement_solver): the left chunk_cA_ columns are
+  // multiplied, finished, reduced over the ranks and restored first; panels [0, chase_hA_) are factored on the side
+  // streams while the main stream multiplies the right chunk
+  bool q_chase_ = false;
+  int chase_hA_ = 0, chase_cA_ = 0, chase_ntileA_ = 0, chase_ntile_ = 0;
+  hipEvent_t ev_chunk_ = nullptr, ev_syrk2_ = nullptr, ev_syrk3_ = nullptr;
+  bool syrk_events2_pending_ = false;
   long xc_broadcast_calls_ = 0;
   double xc_broadcast_bytes_ = 0;
   DevBuf<uint32_t> resbuf_, xgather_, zero_piece_; // zero_piece_: what k_syrk_fx2 stages for rows/columns outside the image
@@ -493,6 +500,9 @@ public:
     HIP_CHECK(hipEventCreate(&ev_q_done_));
     HIP_CHECK(hipEventCreate(&ev_syrk0_));
     HIP_CHECK(hipEventCreate(&ev_syrk1_));
+    HIP_CHECK(hipEventCreate(&ev_syrk2_));
+    HIP_CHECK(hipEventCreate(&ev_syrk3_));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_chunk_, hipEventDisableTiming));
     build_layout();
     set_default_params();
   }
@@ -519,6 +529,12 @@ public:
       (void)hipEventDestroy(ev_syrk0_);
     if(ev_syrk1_)
       (void)hipEventDestroy(ev_syrk1_);
+    if(ev_syrk2_)
+      (void)hipEventDestroy(ev_syrk2_);
+    if(ev_syrk3_)
+      (void)hipEventDestroy(ev_syrk3_);
+    if(ev_chunk_)
+      (void)hipEventDestroy(ev_chunk_);
     if(stream_main_)
       (void)hipStreamDestroy(stream_main_);
   }
@@ -728,6 +744,32 @@ private:
     if(dist_cholq_)
       qpanel_msg_.alloc(((size_t)N_ * PB + (size_t)PB * PB + PB) * (NL + 1) + 2);
     part2_.alloc((size_t)std::max(Jl_, 1) * N_, NL);
+    {
+      // Chased Q' (opt-in: SDPB_HIP_Q_CHASE=1): the split column is a panel boundary and a tile boundary near the middle.
+      // Built for the ranks of a multi-GPU job, where the chain of diagonal blocks of the replicated Cholesky(Q) is
+      // what every rank waits for; measured (profiles/r04g_*, r04h_*): the product's workgroups hold every VGPR of their
+      // SIMDs, so the chain's single workgroups wait for a workgroup of the product to retire before each of their 3 x 16
+      // launches -- the wait at the join does not shrink for a rank of eight (8.5 -> 9.0 ms, step 54.2 -> 55.4 ms), and
+      // on one rank the 2 ms won at the join (4.1 -> 1.9 ms) cost 0.9 ms of product time.  Not the default anywhere.
+      const int panels = (int)cdiv(N_, PB), step = PB % 16 == 0 ? 1 : (PB % 8 == 0 ? 2 : (PB % 4 == 0 ? 4 : (PB % 2 == 0 ? 8 : 16)));
+      bool want = false;
+      if(const char *e = std::getenv("SDPB_HIP_Q_CHASE"))
+        want = std::atoi(e) != 0;
+      const unsigned tiles = cdiv(N_, 16);
+      chase_ntile_ = (int)(tiles * (tiles + 1) / 2);
+      chase_hA_ = std::max(step, (panels / 2) / step * step);
+      chase_cA_ = PB * chase_hA_;
+      q_chase_ = want && !dist_cholq_ && !(overlap_syrk_ && world_ == 1) && chase_hA_ < panels && chase_cA_ < N_; // the same decision on every rank
+      if(q_chase_)
+        {
+          syrk_tiles_.upload(syrk_tile_order(N_, chase_cA_ / 16, &chase_ntileA_));
+          const int slots = num_cus_ * syrk_waves_per_simd<FX>();
+          const int ns = std::max(syrk_row_splits(chase_ntileA_, (unsigned)Ptot_, slots, SYRK_RB),
+                                  syrk_row_splits(chase_ntile_ - chase_ntileA_, (unsigned)Ptot_, slots, SYRK_RB));
+          if((ns > 1 || SYRK_TOOM4) && syrk_part_.n < (size_t)ns * SYRK_PART_PLANES * acc_stride_)
+            syrk_part_.alloc((size_t)ns * SYRK_PART_PLANES * acc_stride_);
+        }
+    }
   }
 
   void set_default_params()
@@ -814,7 +856,7 @@ public:
        << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
        << ", \"comm.allgather_bytes\": " << xc_allgather_bytes_ << ", \"comm.allreduce_calls\": " << xc_allreduce_calls_
        << ", \"comm.allreduce_bytes\": " << xc_allreduce_bytes_ << ", \"comm.broadcast_calls\": " << xc_broadcast_calls_
-       << ", \"comm.broadcast_bytes\": " << xc_broadcast_bytes_ << ", \"comm.cholesky_Q\": " << (dist_cholq_ ? "\"distributed\"" : "\"replicated\"")
+       << ", \"comm.broadcast_bytes\": " << xc_broadcast_bytes_ << ", \"comm.cholesky_Q\": " << (dist_cholq_ ? "\"distributed\"" : "\"replicated\"") << ", \"comm.q_chase\": " << (q_chase_ ? 1 : 0)
        << ", \"comm.collectives\": " << seq_count_.load() << ", \"comm.sequence_hash\": \"" << std::hex << seq_hash_.load() << std::dec << "\"";
     ss << "}";
     return ss.str();
@@ -1147,10 +1189,12 @@ private:
     if(!syrk_events_pending_)
       return;
     syrk_events_pending_ = false;
-    float ms = 0;
-    if(hipEventElapsedTime(&ms, ev_syrk0_, ev_syrk1_) == hipSuccess)
+    float ms = 0, ms2 = 0;
+    const bool two = syrk_events2_pending_;
+    syrk_events2_pending_ = false;
+    if(hipEventElapsedTime(&ms, ev_syrk0_, ev_syrk1_) == hipSuccess && (!two || hipEventElapsedTime(&ms2, ev_syrk2_, ev_syrk3_) == hipSuccess))
       {
-        syrk_kernel_ms_ += ms;
+        syrk_kernel_ms_ += ms + ms2; // the two column chunks of a chased Q' count as one launch of the product
         syrk_launches_ += 1;
       }
   }
@@ -1199,7 +1243,7 @@ private:
         if(below > 0)
           {
             const unsigned tiles = cdiv(below, 16);
-            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), st, A, p, 0, cyc);
+            launch(k_chol_syrk_down<NL>, dim3(tiles * (tiles + 1) / 2, A.count), dim3(WG), st, A, p, 0, cyc, 0, std::numeric_limits<int>::max());
           }
       }
   }
@@ -1209,13 +1253,17 @@ private:
   // first on `st`; the rest of panel p and of the update run on `st2` while block p+1 is
   // being factored.  Entry: the work before is ordered on st; exit: everything is
   // ordered on st.
-  void blocked_cholesky_lookahead(const Batch &A, const Batch &invd, const Batch &Li, int n, int *fail, hipStream_t st, hipStream_t st2)
+  // Panels [p0, p1) only, the trailing updates confined to the columns below col_hi (the chased Cholesky(Q): the left
+  // chunk of Q is factored before the right one exists; chol_deferred_updates() then brings the right chunk up to date
+  // and a second call takes the remaining panels).  Entry for p0 > 0: diagonal block p0 is up to date on st.
+  void blocked_cholesky_lookahead(const Batch &A, const Batch &invd, const Batch &Li, int n, int *fail, hipStream_t st, hipStream_t st2,
+                                  int p0 = 0, int p1 = -1, int col_hi = std::numeric_limits<int>::max())
   {
-    const int panels = cdiv(n, PB);
+    const int panels = p1 < 0 ? (int)cdiv(n, PB) : p1;
     constexpr int STRIP_ROW_TILES = PB / TR, STRIP_TILES = (PB / 16) * (PB / 16 + 1) / 2;
     unsigned long long *const cyc = nullptr; // Q is not an SDP block
-    launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, 0, fail, cyc);
-    for(int p = 0; p < panels; ++p)
+    launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, p0, fail, cyc);
+    for(int p = p0; p < panels; ++p)
       {
         // here: diagonal block p is queued on st, and st has joined the bulk of step p-1
         const int below = n - PB * (p + 1), above = PB * p;
@@ -1230,14 +1278,34 @@ private:
         HIP_CHECK(hipStreamWaitEvent(st2, ev_la_strip_, 0));
         if(row_tiles > strip_rows)
           launch(k_chol_panel_solve<NL>, dim3(row_tiles - strip_rows, 1), dim3(WG), st2, A, Li, p, strip_rows, cyc);
-        if(ntile > strip_tiles)
-          launch(k_chol_syrk_down<NL>, dim3(ntile - strip_tiles, 1), dim3(WG), st2, A, p, strip_tiles, cyc);
+        if(ntile > strip_tiles && PB * (p + 1) < col_hi)
+          launch(k_chol_syrk_down<NL>, dim3(ntile - strip_tiles, 1), dim3(WG), st2, A, p, strip_tiles, cyc, 0, col_hi);
         HIP_CHECK(hipEventRecord(ev_la_bulk_, st2));
-        if(strip_tiles > 0) // leading PB x PB block of the trailing update
+        // (the last panel of a range that ends before the matrix does leaves the next diagonal block to the deferred updates)
+        if(strip_tiles > 0 && p + 1 < panels) // leading PB x PB block of the trailing update
           launch(k_chol_strip_update<NL>, dim3(cdiv((size_t)PB * (PB + 1) / 2, WG / (PB <= WG ? WG / PB : 1))), dim3(WG), st, A, p);
         if(p + 1 < panels)
           launch(k_chol_inv_lds<NL>, dim3(1), dim3(CI_T), st, A, invd, Li, p + 1, fail, cyc); // overlaps the bulk of step p
         HIP_CHECK(hipStreamWaitEvent(st, ev_la_bulk_, 0));
+      }
+  }
+  // Panels [0, h) applied to the columns from col_lo = PB h on, in the order and with the kernels the look-ahead
+  // factorisation itself would have used (every entry sees the same operations: the factor is bit-identical), on st2.
+  void chol_deferred_updates(const Batch &A, int n, int h, hipStream_t st2)
+  {
+    constexpr int STRIP_TILES = (PB / 16) * (PB / 16 + 1) / 2;
+    unsigned long long *const cyc = nullptr;
+    const int col_lo = PB * h;
+    for(int p = 0; p < h; ++p)
+      {
+        const int below = n - PB * (p + 1);
+        const unsigned tiles = below > 0 ? cdiv(below, 16) : 0;
+        const int ntile = (int)(tiles * (tiles + 1) / 2);
+        const int strip_tiles = std::min(ntile, STRIP_TILES);
+        if(p + 1 == h && strip_tiles > 0)
+          launch(k_chol_strip_update<NL>, dim3(cdiv((size_t)PB * (PB + 1) / 2, WG / (PB <= WG ? WG / PB : 1))), dim3(WG), st2, A, p);
+        if(ntile > strip_tiles)
+          launch(k_chol_syrk_down<NL>, dim3(ntile - strip_tiles, 1), dim3(WG), st2, A, p, strip_tiles, cyc, col_lo, std::numeric_limits<int>::max());
       }
   }
   // X := X L^{-T} (rows of X are the right-hand sides)
@@ -1470,7 +1538,51 @@ private:
       if(cnt)
         launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT_.cptr(), cnt, N_, // one element per lane: streams at HBM rate
                invnorms_.cptr(), fx_.p, fx_stride_);
-      const unsigned tiles = cdiv(N_, 16);
+      int *qflags = flags_.p + 2 * std::max(Jl_, 1);
+      HIP_CHECK(hipMemsetAsync(qflags, 0, 4 * sizeof(int), stream_));
+      // unbias + un-normalise the columns [c0, c1) of the lower triangle into Q (check of the diagonal included)
+      auto finish_Q_columns = [&](int c0, int c1) {
+        const size_t idx0 = (size_t)c0 * N_, idx1 = (size_t)c1 * N_;
+        launch(k_syrk_unbias<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, acc_.p, acc_stride_, N_, Ptot_global_, idx0, idx1);
+        launch(k_restore_Q<NL, FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_, norms_.cptr(),
+               Q_.ptr(), qflags + 1, idx0, idx1);
+      };
+      if(q_chase_)
+        {
+          // Q' in two column chunks with Cholesky(Q) chasing it: while the main stream multiplies (and, with several
+          // ranks, reduces) the right chunk, the side streams factor the panels of the left one -- half of the chain
+          // of diagonal blocks, the part of Cholesky(Q) that no number of GPUs shortens, moves behind the product.
+          // Every rank issues the same collectives in the same order (two all-reduces instead of one).
+          const uint32_t *tl = (const uint32_t *)syrk_tiles_.p;
+          const int cA = chase_cA_;
+          if(cnt)
+            {
+              syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_, toomU_.p);
+              resolve_syrk_events();
+              HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
+              syrk_G(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, tl, syrk_part_, toomU_.p, chase_ntileA_, 0, cA);
+              HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
+            }
+          else
+            HIP_CHECK(hipMemsetAsync(acc_.p, 0, acc_.n * sizeof(uint32_t), stream_));
+          if(world_ > 1)
+            reduce_Q_accumulators(0, cA, true);
+          finish_Q_columns(0, cA);
+          cholesky_Q_chase_left();
+          if(cnt)
+            {
+              HIP_CHECK(hipEventRecord(ev_syrk2_, stream_));
+              syrk_G(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, tl + chase_ntileA_, syrk_part_, toomU_.p,
+                     chase_ntile_ - chase_ntileA_, cA, N_);
+              HIP_CHECK(hipEventRecord(ev_syrk3_, stream_));
+              syrk_events_pending_ = syrk_events2_pending_ = true;
+            }
+          if(world_ > 1)
+            reduce_Q_accumulators(cA, N_, false);
+          finish_Q_columns(cA, N_);
+          cholesky_Q_chase_right();
+          return;
+        }
       if(cnt)
         {
           syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_, toomU_.p);
@@ -1486,11 +1598,7 @@ private:
         HIP_CHECK(hipMemsetAsync(acc_.p, 0, acc_.n * sizeof(uint32_t), stream_));
       if(world_ > 1)
         reduce_Q_accumulators();
-      int *qflags = flags_.p + 2 * std::max(Jl_, 1);
-      HIP_CHECK(hipMemsetAsync(qflags, 0, 4 * sizeof(int), stream_));
-      launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, acc_.p, acc_stride_, N_, Ptot_global_);
-      launch(k_restore_Q<NL, FX>, dim3(cdiv((size_t)N_ * N_, WG)), dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_,
-             norms_.cptr(), Q_.ptr(), qflags + 1);
+      finish_Q_columns(0, N_);
       if(side)
         {
           // Cholesky(Q) follows on the same (side) stream, look-ahead bulk on the third one
@@ -1534,13 +1642,20 @@ private:
   }
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
   // that fills the last round of resident workgroups better; `part` grows on demand
+  // ntile_sub >= 0: only the `ntile_sub` tiles tiles_dev points at, which cover the columns [col0, col1) of the lower
+  // triangle (a chunk of the chased Q'; the list comes from syrk_tile_order(N, split))
   void syrk_G(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tiles_dev,
-              DevBuf<uint32_t> &part, const uint32_t *toomU = nullptr)
+              DevBuf<uint32_t> &part, const uint32_t *toomU = nullptr, int ntile_sub = -1, int col0 = 0, int col1 = -1)
   {
     if(SYRK_TOOM4 && !toomU)
       throw SolverError(4, "syrk_G: the Toom-4 image needs the column terms of syrk_column_sums");
     const unsigned tiles = cdiv(N, 16);
-    const int ntile = (int)(tiles * (tiles + 1) / 2);
+    const int ntile = ntile_sub >= 0 ? ntile_sub : (int)(tiles * (tiles + 1) / 2);
+    if(col1 < 0)
+      col1 = N;
+    const size_t idx0 = (size_t)col0 * N, idx1 = (size_t)col1 * N;
+    if(ntile == 0 || idx1 <= idx0)
+      return;
     const int slots = num_cus_ * syrk_waves_per_simd<FX>();
     const int nsplit = syrk_row_splits(ntile, nrows, slots, SYRK_RB);
     const unsigned rps = cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB;
@@ -1555,8 +1670,8 @@ private:
       {
         launch(k_syrk_fx2<FX, SYRK_RB, true>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out,
                acc_stride, tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
-        launch(k_syrk4_finish<FX>, dim3(cdiv((size_t)N * N, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, (const uint32_t *)toomU, acc,
-               acc_stride, N);
+        launch(k_syrk4_finish<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, (const uint32_t *)toomU, acc,
+               acc_stride, N, idx0, idx1);
         return;
       }
     else if constexpr(SYRK_TWO_LEVEL)
@@ -1566,7 +1681,7 @@ private:
       launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
              tiles_dev, ntile, nsplit, rps);
     if(nsplit > 1)
-      launch(k_syrk_reduce<FX>, dim3(cdiv((size_t)N * N, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, acc, acc_stride, N);
+      launch(k_syrk_reduce<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, acc, acc_stride, N, idx0, idx1);
   }
   // S_n = sum_r a'_rn behind the N x N block of acc (kernels.hpp: k_fx_colsum)
   void syrk_column_sums(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, uint32_t *partial,
@@ -1592,17 +1707,20 @@ private:
     launch(k_fx_colsum_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride);
   }
   // exact cross-GPU sum of the fixed-point Q' images
-  void reduce_Q_accumulators()
+  void reduce_Q_accumulators(int c0 = 0, int c1 = -1, bool with_sums = true)
   {
-    // lower triangle + column sums only: (N(N+1)/2 + N) entries x ACCW planes of 64-bit lanes
-    const size_t T = (size_t)N_ * (N_ + 1) / 2 + N_;
-    const dim3 grid(cdiv(N_, WG), N_ + 1);
-    launch(k_widen_tri_u64<0>, grid, dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_, (int)ACCW, acc64_.p);
+    // lower triangle of the columns [c0, c1) (+ the N column sums): entries x ACCW planes of 64-bit lanes
+    if(c1 < 0)
+      c1 = N_;
+    const size_t T = tri_packed_offset(N_, c1) - tri_packed_offset(N_, c0) + (with_sums ? (size_t)N_ : 0);
+    const dim3 grid(cdiv(N_, WG), c1 - c0 + (with_sums ? 1 : 0));
+    launch(k_widen_tri_u64<0>, grid, dim3(WG), stream_, (const uint32_t *)acc_.p, acc_stride_, N_, (int)ACCW, acc64_.p, c0, c1, (int)with_sums);
     xc_allreduce_calls_ += 1;
     xc_allreduce_bytes_ += (double)(T * ACCW * 8);
     note_collective(COLL_ALLREDUCE, T * ACCW * 8, -1);
     comm().allreduce_sum_u64(acc64_.p, T * ACCW, stream_);
-    launch(k_narrow_tri_carry<0>, grid, dim3(WG), stream_, (const unsigned long long *)acc64_.p, N_, (int)ACCW, acc_.p, acc_stride_);
+    launch(k_narrow_tri_carry<0>, grid, dim3(WG), stream_, (const unsigned long long *)acc64_.p, N_, (int)ACCW, acc_.p, acc_stride_, c0, c1,
+           (int)with_sums);
   }
   // in-place broadcast on the main stream through whatever the exchange runs on
   void xbroadcast(uint32_t *buf, size_t words, int root)
@@ -1705,6 +1823,34 @@ private:
   // the main stream goes on with -XY, mu, R-error and the part of the predictor that does
   // not need Q (R, Z, the Schur right-hand side, L^{-1} dx, P^T dx); join_cholesky_Q()
   // joins before the first Q solve.
+  // The chased Cholesky(Q), first half: panels [0, chase_hA_) of the left chunk on the side streams (the main stream
+  // goes on with the right chunk of Q').  Second half: the left panels applied to the right chunk, then the rest.
+  void cholesky_Q_chase_left()
+  {
+    int *qflags = flags_.p + 2 * std::max(Jl_, 1);
+    HIP_CHECK(hipEventRecord(ev_q_ready_, stream_));
+    HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_q_ready_, 0));
+    blocked_cholesky_lookahead(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags, stream_q_, stream_q2_, 0, chase_hA_, chase_cA_);
+  }
+  void cholesky_Q_chase_right()
+  {
+    int *qflags = flags_.p + 2 * std::max(Jl_, 1);
+    HIP_CHECK(hipEventRecord(ev_chunk_, stream_)); // the right chunk of Q is in place
+    HIP_CHECK(hipStreamWaitEvent(stream_q2_, ev_chunk_, 0));
+    chol_deferred_updates(QB(), N_, chase_hA_, stream_q2_); // in order behind the left half's own bulk updates
+    HIP_CHECK(hipEventRecord(ev_la_bulk_, stream_q2_));
+    HIP_CHECK(hipStreamWaitEvent(stream_q_, ev_la_bulk_, 0));
+    blocked_cholesky_lookahead(QB(), vecQB(invdQ_), Batch{LiQ_.ptr(), d_Q_.p, 1}, N_, qflags, stream_q_, stream_q2_, chase_hA_);
+    HIP_CHECK(hipEventRecord(ev_q_done_, stream_q_));
+    q_pending_ = true;
+    if(stream_beside_ && !beside_active_)
+      {
+        HIP_CHECK(hipEventRecord(ev_beside_, stream_));
+        HIP_CHECK(hipStreamWaitEvent(stream_beside_, ev_beside_, 0));
+        stream_ = stream_beside_;
+        beside_active_ = true;
+      }
+  }
   void cholesky_Q_async()
   {
     int *qflags = flags_.p + 2 * std::max(Jl_, 1);
@@ -2475,9 +2621,10 @@ public:
     syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, spart, tu.p);
     qf.alloc(4);
     HIP_CHECK(hipMemsetAsync(qf.p, 0, 4 * sizeof(int), stream_));
-    launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows);
+    launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows, (size_t)0,
+           (size_t)cols * cols);
     launch(k_restore_Q<NL, FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, (const uint32_t *)acc.p, as, cols, nrm.cptr(),
-           Q.ptr(), qf.p + 1);
+           Q.ptr(), qf.p + 1, (size_t)0, (size_t)cols * cols);
     HIP_CHECK(hipStreamSynchronize(stream_));
     const std::vector<int> flags = qf.download();
     if(flags[1]) // compute_Q.cxx:65-91
@@ -2548,7 +2695,8 @@ public:
     tl.upload(syrk_tile_order(cols));
     DevBuf<uint32_t> part;
     syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
-    launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows);
+    launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows, (size_t)0,
+           (size_t)cols * cols);
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<uint32_t> a = acc.download();
     std::string out;

@@ -99,6 +99,28 @@ def test_multi_panel_paths_with_4_column_panels(name, limit):
     s.close()
 
 
+@pytest.mark.parametrize("name,limit", [("singlet_cT", 3), ("dfibo", 3)])
+def test_chased_cholesky_Q_with_4_column_panels(name, limit, monkeypatch):
+    """Q' in two column chunks and Cholesky(Q) chasing it (SDPB_HIP_Q_CHASE=1) on one rank of the PB = 4 build: N = 20 /
+    19 = five panels, the first four (one 16-column tile column) factored before the fifth is restored, then applied
+    to it.  Same trace as the reference and the same bits as the one-piece schedule."""
+    sdp, meta, iters, out = parity.load_case(name)
+    traces = []
+    for chase in ("1", "0"):
+        monkeypatch.setenv("SDPB_HIP_Q_CHASE", chase)
+        s = SDPSolver(sdp, meta["precision"], meta["params"], lib_path=libs.emu_lib(panel=4))
+        t = []
+        for rec in iters[:limit]:
+            assert not s.iterate(), (name, rec["iteration"], s.terminate_reason)
+            bad, _ = parity.compare_iteration(s.scalars(), rec)
+            assert not bad, (rec["iteration"], bad)
+            t.append(s.scalars())
+        assert s.timers()["comm.q_chase"] == int(chase)
+        traces.append(t)
+        s.close()
+    assert traces[0] == traces[1]
+
+
 def test_emulated_library_matches_oracle_on_dim6_blocks():
     """BASELINE.json config 5 shape (m_j = 6, K_j = 2: 21 (r,s) pairs per block) at reduced size
     and precision 512: exercises the (r,s) tile decoding of pairings, Schur assembly, constraint

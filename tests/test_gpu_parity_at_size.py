@@ -251,3 +251,26 @@ def test_concurrent_streams_give_the_same_bits_as_one_stream(monkeypatch):
         traces.append(t)
         s.close()
     assert traces[0] == traces[1]
+
+
+def test_chased_cholesky_Q_gives_the_same_bits(monkeypatch):
+    """Q' in two column chunks with Cholesky(Q) chasing it (SDPB_HIP_Q_CHASE=1, opt-in): the left
+    panels are factored while the right chunk is multiplied, then applied to it.  Every entry of Q sees the same
+    operations in the same order as in the one-piece schedule, so whole iterations agree to the last bit (C4 x0.25:
+    N = 250, eight panels, split after the fourth; the single-stream run covers the ordering the events enforce)."""
+    c = _shape("C4", 0.25)
+    traces = []
+    for chase, single in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("SDPB_HIP_Q_CHASE", chase)
+        monkeypatch.setenv("SDPB_HIP_SINGLE_STREAM", single)
+        sdp, s, _ = _pair(c, oracle=False)
+        t = []
+        for _ in range(3):
+            assert not s.iterate()
+            t.append(s.scalars())
+        t.append(s.array("dy")[:64])
+        traces.append(t)
+        assert s.timers()["comm.q_chase"] == int(chase)
+        s.close()
+    assert traces[0] == traces[1] == traces[2]
+

@@ -32,6 +32,24 @@ def test_cholesky_Q_distributed_over_the_ranks(name, n_iter, world):
         assert not bad, (want["iteration"], bad)
 
 
+@pytest.mark.parametrize("name,n_iter,world", [("singlet_cT", 3, 2), ("dfibo", 3, 3)])
+def test_chased_cholesky_Q_over_the_ranks(name, n_iter, world):
+    """Q' in two column chunks (two all-reduces) with the replicated Cholesky(Q) chasing it (SDPB_HIP_Q_CHASE=1; opt-in, a
+    measured loss on the hardware: DESIGN section 9) on the 4-column-panel build: N = 20 / 19 = five panels, the left four
+    (16 columns = one tile column) are factored before the right one is reduced.  Same trace as the reference, ranks
+    bit-identical, and the same bits as the one-piece schedule."""
+    sdp, _, _, _, iters = _load(name)
+    results = run_ranks(world, name, n_iter, timeout=900, gpu=False, env={"SDPB_HIP_Q_CHASE": "1"}, emu_panel=4)
+    check_ranks(results, world, sdp.J)
+    assert all(r[3]["comm.q_chase"] == 1 and r[3]["comm.allreduce_calls"] == 2 * n_iter for r in results)
+    for got, want in zip(results[0][2], iters):
+        bad, _ = parity.compare_iteration(got, want)
+        assert not bad, (want["iteration"], bad)
+    plain = run_ranks(world, name, n_iter, timeout=900, gpu=False, env={"SDPB_HIP_Q_CHASE": "0"}, emu_panel=4)
+    assert plain[0][3]["comm.q_chase"] == 0 and plain[0][3]["comm.allreduce_calls"] == n_iter
+    assert plain[0][2] == results[0][2]
+
+
 def test_ranks_that_fall_out_of_step_fail_alike():
     """The collective-sequence self-check (kernels.hpp: XW_SEQ_LO; include/sdpb_hip.h: sdpb_hip_progress): rank 1's
     hash of the (kind, bytes, root) sequence is perturbed (SDPB_HIP_TEST_SEQ_FAULT=1 — the collectives themselves stay
