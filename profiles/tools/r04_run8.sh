@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 4: the pivot's reciprocal square root (k_chol_inv_lds) and the Householder step's square root + reciprocal (k_tridiag)
+# computed by a whole wavefront (mw_wave.hpp)
+set +e
+O=gpurun_out/r04j; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log; tail -3 $O/gpu_tests.log
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_C4_20.json 2>> $O/err.log
+SDPB_HIP_SYRK_SPLITS=16 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_C4_20_splits16.json 2>> $O/err.log
+timeout 600 python bench.py --simulate-world 8 --steps 10 --warmup 3 --no-cpu-baseline > $O/sim_world8.json 2>> $O/err.log
+timeout 600 python bench.py --workload golden:singlet_cT --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_singlet_cT.json 2>> $O/err.log
+timeout 600 python bench.py --workload C3 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_C3.json 2>> $O/err.log
+timeout 900 python bench.py --workload C5slice --scale 0.5 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_C5slice_x0.5.json 2>> $O/err.log
+for f in $O/*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{"metric"')][-1]
+    st=d.get("stage_ms_profiled_iteration",{})
+    print(sys.argv[1].split('/')[-1], d.get("value"), d.get("ms_per_step"), "join", st.get("initializeSchurComplementSolver.Cholesky_Q(join)"), "chol", st.get("choleskyDecomposition"), st.get("initializeSchurComplementSolver.Q.cholesky"), "steplen", st.get("stepLength"), "syrk", d["roofline"].get("launch_ms"), (d.get("parity_gate") or {}).get("worst_log2_rel"))
+except Exception as e: print(sys.argv[1], "unreadable", e)
+PY
+done
+tail -5 $O/err.log

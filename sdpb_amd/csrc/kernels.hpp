@@ -12,6 +12,7 @@
 // Reference functions each kernel replaces are cited at the kernel.
 #pragma once
 #include "dev.hpp"
+#include "mw_wave.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -213,6 +214,7 @@ template <int NL, int OP, class F> __global__ void __launch_bounds__(WG) k_reduc
 constexpr int PB = SDPB_PB; // panel width (tests also build a PB = 4 variant to exercise ragged multi-panel paths)
 constexpr int CI_T = 256;      // lanes of the diagonal-block kernel: one wavefront per SIMD of a CU
 constexpr int CI_D0 = CI_T - 64; // first lane of the wavefront that owns the diagonal
+static_assert(CI_D0 % 64 == 0 && PB <= 64, "lane k of the diagonal's wavefront owns (k, k)");
 constexpr int CI_NPK = PB * (PB + 1) / 2;                             // packed lower triangle (LDS images)
 // Off-diagonal elements are dealt to lanes as a round-robin tournament: round m (PB-1 of
 // them) pairs up all PB indices, and a lane takes up to three pairs of ONE round, so the
@@ -389,6 +391,36 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
     {
       // (1) pivot: X_kk = 1/L_kk = rsqrt(d_k)
       Mw<NL> dk = mw::zero<NL>();
+#if defined(__HIP_DEVICE_COMPILE__)
+      // The diagonal's wavefront computes the ONE reciprocal square root together (mw_wave.hpp: the same Newton ladder
+      // with a limb per lane, bit-identical to mw::rsqrt; 3.0 instead of 4.8-6 us at 576 bits, 4.5 instead of 11-15 us
+      // at 1088: profiles/r04i_ubench_wave_rsqrt.txt) — it is the longest link of the pivot chain.  Lane k of that
+      // wavefront owns (k, k); the branch is uniform over the wavefront.
+      if(diag_lane)
+        {
+          if(e0.r == k)
+            dk = mw::acc_result(e0.acc);
+          const int owner = k; // CI_D0 is a multiple of the wavefront size
+          const uint32_t bad = mw::wv::bcast((mw::is_zero(dk) || dk.neg) ? 1u : 0u, owner);
+          if(bad)
+            {
+              if(e0.r == k)
+                s_fail = k0 + k + 1;
+            }
+          else
+            {
+              const Mw<NL> r = mw::wv::rsqrt<NL>(dk, owner);
+              if(e0.r == k)
+                {
+#pragma unroll
+                  for(int l = 0; l < NL; ++l)
+                    s_inv[l] = r.m[l];
+                  s_inv[NL] = (uint32_t)r.e;
+                  s_inv[NL + 1] = r.neg;
+                }
+            }
+        }
+#else
       if(diag_lane && e0.r == k)
         {
           dk = mw::acc_result(e0.acc);
@@ -404,6 +436,7 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
               s_inv[NL + 1] = r.neg;
             }
         }
+#endif
       __syncthreads();
       if(s_fail)
         {
@@ -3475,6 +3508,25 @@ template <int NL, int T> __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TR
             mw::store<NL>(E.p, oe + i, mat_ld<NL>(A, d, i, l));
           continue;
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+      // the square root and the reciprocal of a Householder step are ONE number each — 11 + 4 us on one lane at 576
+      // bits, the longest link of the step: the first wavefront computes them together (mw_wave.hpp, same bits)
+      if(t < 64)
+        {
+          const Mw<NL> f = mat_ld<NL>(A, d, i, l);
+          Mw<NL> g = mw::wv::sqrt<NL>(h0, 0);
+          if(!f.neg)
+            g = mw::neg(g);
+          const Mw<NL> h = mw::sub(h0, mw::mul(f, g));
+          const Mw<NL> hinv1 = mw::wv::rcp<NL>(h, 0);
+          if(t == 0)
+            {
+              mw::store<NL>(E.p, oe + i, g);
+              mat_st<NL>(A, d, i, l, mw::sub(f, g));
+              s_hinv = hinv1;
+            }
+        }
+#else
       if(t == 0)
         {
           const Mw<NL> f = mat_ld<NL>(A, d, i, l);
@@ -3486,6 +3538,7 @@ template <int NL, int T> __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TR
           mat_st<NL>(A, d, i, l, mw::sub(f, g));
           s_hinv = mw::rcp(h);
         }
+#endif
       __syncthreads();
       const Mw<NL> hinv = s_hinv;
       // e[j] = (A_sub u)_j / h with teams of G lanes per row j
