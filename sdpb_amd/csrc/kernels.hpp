@@ -278,7 +278,9 @@ template <int NL> MW_HD void ci_init_offdiag(CiElem<NL> &el, int m, int i, int n
     mw::acc_add(el.acc, mat_ld<NL>(A, d, k0 + el.r, k0 + el.c));
 }
 // (2) finish column k of L and row k of X:  L(r,k) = acc / L_kk,  X(k,c) = -acc / L_kk
-template <int NL> MW_HD void ci_finish(CiElem<NL> &el, int k, int n, uint32_t *sL, uint32_t *sX, const uint32_t *s_inv)
+// `sum` = acc_result(el.acc), taken by the caller BEFORE the barrier that publishes the pivot: the normalisation does
+// not depend on the pivot, so it runs while the diagonal's wavefront is busy with the reciprocal square root
+template <int NL> MW_HD void ci_finish(CiElem<NL> &el, const Mw<NL> &sum, int k, int n, uint32_t *sL, uint32_t *sX, const uint32_t *s_inv)
 {
   const bool colk = el.c == k && el.r > k, rowk = el.r == k && el.c < k;
   if(!(colk || rowk))
@@ -289,7 +291,7 @@ template <int NL> MW_HD void ci_finish(CiElem<NL> &el, int k, int n, uint32_t *s
     inv.m[l] = s_inv[l];
   inv.e = (int32_t)s_inv[NL];
   inv.neg = s_inv[NL + 1];
-  Mw<NL> v = mw::mul(mw::acc_result(el.acc), inv);
+  Mw<NL> v = mw::mul(sum, inv);
   v.neg ^= (rowk && !mw::is_zero(v)) ? 1u : 0u;
   ci_st<NL>(rowk ? sX : sL, SDPB_PK(el.r, el.c), v); // one code path for both kinds (lanes of a wavefront hold both)
   el.acc = mw::acc_zero<NL>();
@@ -389,6 +391,18 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
   __syncthreads();
   for(int k = 0; k < n; ++k)
     {
+      // (0) the off-diagonal lanes pick the element they will finish at this pivot (at most one per lane lies in column
+      //     k or row k) and normalise its sum now, beside the pivot's reciprocal square root
+      bool m0 = false, m1 = false, m2 = false;
+      Mw<NL> fsum = mw::zero<NL>();
+      if(!diag_lane)
+        {
+          m0 = e0.r >= 0 && (e0.r == k || e0.c == k) && e0.r >= k;
+          m1 = e1.r >= 0 && (e1.r == k || e1.c == k) && e1.r >= k;
+          m2 = e2.r >= 0 && (e2.r == k || e2.c == k) && e2.r >= k;
+          if(m0 || m1 || m2)
+            fsum = mw::acc_result(m0 ? e0.acc : (m1 ? e1.acc : e2.acc));
+        }
       // (1) pivot: X_kk = 1/L_kk = rsqrt(d_k)
       Mw<NL> dk = mw::zero<NL>();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -462,14 +476,11 @@ template <int NL> __global__ void __launch_bounds__(CI_T) k_chol_inv_lds(Batch A
         }
       else
         {
-          // at most one of the lane's elements lies in column k or row k: pick it, finish it once
-          const bool m0 = e0.r >= 0 && (e0.r == k || e0.c == k) && e0.r >= k;
-          const bool m1 = e1.r >= 0 && (e1.r == k || e1.c == k) && e1.r >= k;
-          const bool m2 = e2.r >= 0 && (e2.r == k || e2.c == k) && e2.r >= k;
+          // at most one of the lane's elements lies in column k or row k: finish it once
           if(m0 || m1 || m2)
             {
               CiElem<NL> sel = m0 ? e0 : (m1 ? e1 : e2);
-              ci_finish<NL>(sel, k, n, sL, sX, s_inv);
+              ci_finish<NL>(sel, fsum, k, n, sL, sX, s_inv);
               if(m0)
                 e0.acc = sel.acc;
               else if(m1)
@@ -1399,12 +1410,22 @@ __global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Bat
     return;
   const MatDesc ds = S.d[j];
   const int P = ds.rows, K = blk[j].K;
+  // one lane per entry of the LOWER triangle, packed column by column (rows fastest: a wavefront walks down a
+  // column, so `row` below stays the fast lane index).  Round 4: the P x P grid left every lane above the diagonal
+  // idle — the kernel is bound by its 8 multi-word products per entry (1.4 * 10^7 on C4 = 0.21 ms at the chip's
+  // product rate, twice its 0.11 ms of HBM time), not by HBM, and spent them at half occupancy.
   const size_t idx = (size_t)strip * WG + threadIdx.x;
-  if(idx >= (size_t)P * P)
+  if(idx >= (size_t)P * (P + 1) / 2)
     return;
-  const int R = (int)(idx % P), C = (int)(idx / P);
-  if(R < C)
-    return;
+  // column C: the largest C with C P - C (C - 1) / 2 <= idx
+  const double tp1 = 2.0 * P + 1.0;
+  int C = (int)((tp1 - mw::host_device_sqrt(tp1 * tp1 - 8.0 * (double)idx)) * 0.5);
+  C = C < 0 ? 0 : (C > P - 1 ? P - 1 : C);
+  while(C > 0 && (size_t)C * P - (size_t)C * (C - 1) / 2 > idx)
+    --C;
+  while(C + 1 < P && (size_t)(C + 1) * P - (size_t)(C + 1) * C / 2 <= idx)
+    ++C;
+  const int R = C + (int)(idx - ((size_t)C * P - (size_t)C * (C - 1) / 2));
   int c0, r0, row, c1, r1, col;
   decode_p(R, K, c0, r0, row);
   decode_p(C, K, c1, r1, col);

@@ -1499,7 +1499,7 @@ private:
   {
     {
       Timer t(this, "initializeSchurComplementSolver.schur_complement");
-      const unsigned strips = cdiv((size_t)max_P_ * max_P_, WG);
+      const unsigned strips = cdiv((size_t)max_P_ * (max_P_ + 1) / 2, WG); // lower triangle, packed
       launch(k_schur_complement<NL>, dim3(8 * cdiv(Jl_, 8) * strips), dim3(WG), stream_, pairB(AX_), pairB(AY_), schurB(), d_blk_.p,
              (int)strips);
     }
