@@ -14,5 +14,5 @@ for name, _, v in rows:
     a[0] += 1
     a[1] += v
 print(f"# kernel, launches, avg {sys.argv[2]} per launch [KB]")
-for name, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1] / kv[1][0])[:25]:
+for name, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1] / kv[1][0])[:70]:
     print(f"{name[:80]:80s} {n:6d} {tot / n:16.1f}")

@@ -1448,10 +1448,13 @@ __global__ void __launch_bounds__(WG) k_schur_complement(Batch AX, Batch AY, Bat
 #undef AXT
 #undef AYT
     }
+  // The lower triangle only.  The reference mirrors it (MakeSymmetric LOWER, :121) for El::Cholesky; here S_j goes
+  // straight into blocked_cholesky, which reads the lower triangle and leaves zeros above the diagonal — the mirror
+  // store was dead work, and a costly one: lanes of a wavefront run down a column, so the mirrored entries lie a whole
+  // row apart, 64 cache lines per store instruction and word plane (WRITE_SIZE 0.77 GB per launch for 0.28 GB of S,
+  // profiles/r04l_pmc_WRITE_SIZE.txt).
   const Mw<NL> e = mw::mul_2exp(mw::acc_result(es), -2);
   mat_st<NL>(S, ds, R, C, e);
-  if(R != C)
-    mat_st<NL>(S, ds, C, R, e);
 }
 
 // dual_residues[p] = c[p] - sum_b diag(A_Y tile)[k]   (the -(B y)[p] term is added by

@@ -63,7 +63,7 @@ def test_gpu_matches_live_oracle_beyond_one_panel(name, c, iters):
     o.close()
 
 
-FIXTURES = sorted(f for f in (os.listdir(SYN) if os.path.isdir(SYN) else []) if f.endswith(".json"))
+FIXTURES = sorted(f for f in (os.listdir(SYN) if os.path.isdir(SYN) else []) if f.endswith(".json") and f != "gate_thresholds.json")
 
 
 @pytest.mark.parametrize("fixture", FIXTURES)
