@@ -2529,14 +2529,18 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
 #define SDPB_SYRK_WAVES (FX <= 16 ? 3 : 2) // 3 waves x 168 VGPRs hold the staging registers of the pipeline without spills
 #endif
 template <int FX> constexpr int syrk_waves_per_simd() { return SDPB_SYRK_WAVES; }
-// nsplit in [1, 16]: fewest splits within 2% of the best occupancy of the last round
+// nsplit in [1, 32]: fewest splits within 2% of the best occupancy of the last round.  (Up to 16 until round 4: with
+// N = 100 the output has 28 tiles, and 16 splits filled 448 of the chip's 768 workgroup slots — C3's product took
+// 2.08 ms at 8 splits, 3.8 at 4, 15 at 1: profiles/r04k_syrk_row_splits.txt; the row floor of 64 passes per split
+// still applies.)
+constexpr int SYRK_MAX_SPLITS = 32;
 inline int syrk_row_splits(int ntile, unsigned nrows, int slots, int rb)
 {
   if(const char *env = std::getenv("SDPB_HIP_SYRK_SPLITS")) // tests force the split path on small inputs
-    return std::max(1, std::min(16, std::atoi(env)));
+    return std::max(1, std::min(SYRK_MAX_SPLITS, std::atoi(env)));
   int best = 1;
   double best_eff = 0;
-  for(int s = 1; s <= 16; ++s)
+  for(int s = 1; s <= SYRK_MAX_SPLITS; ++s)
     {
       if(s > 1 && nrows / (unsigned)s < 64u * (unsigned)rb)
         break;
