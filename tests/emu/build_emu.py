@@ -53,14 +53,22 @@ def _run(cmd):
         raise RuntimeError("emu build failed")
 
 
-def build(force=False, panel=None):
+VARIANTS = {"notoom4": (["-DSDPB_SYRK_NO_TOOM4"], (18,))}   # name -> (extra flags, limb counts): documented build options kept alive
+
+
+def build(force=False, panel=None, variant=None):
     """panel=None: the product configuration; panel=4: same sources with 4-column panels so that
-    even the small golden SDPs run through the multi-panel Cholesky / triangular-solve paths."""
+    even the small golden SDPs run through the multi-panel Cholesky / triangular-solve paths;
+    variant="notoom4": -DSDPB_SYRK_NO_TOOM4 (the two-level Karatsuba image at every precision)."""
     global OUT, LIB
     base_out = os.path.join(HERE, "_build")
     OUT = base_out if panel is None else os.path.join(base_out, f"pb{panel}")
-    LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
     extra = [] if panel is None else [f"-DSDPB_PB={panel}"]
+    limbs = LIMBS if panel is None else (26,)
+    if variant is not None:
+        OUT = os.path.join(base_out, variant)
+        extra, limbs = list(VARIANTS[variant][0]), VARIANTS[variant][1]
+    LIB = os.path.join(OUT, "libsdpb_hip_emu.so")
     os.makedirs(OUT, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu.hpp"),
                                                                  os.path.join(HERE, "hip_emu.cpp"),
@@ -69,13 +77,13 @@ def build(force=False, panel=None):
     sys.path.insert(0, ROOT)
     from sdpb_amd.build import EXTRA_FLAGS as product_flags
     jobs, objs, todo = [], [], []
-    for nl in (LIMBS if panel is None else (26,)):
+    for nl in limbs:
         obj = os.path.join(OUT, f"solver_{nl}.o")
         objs.append(obj)
         if force or _stale(obj, digest):
             todo.append(obj)
             # same per-width flags as the product build (16-column panels above 1024 bits) unless a panel width is forced
-            per_nl = [] if panel is not None else product_flags.get(nl, [])
+            per_nl = [] if (panel is not None or variant is not None) else product_flags.get(nl, [])
             jobs.append([CXX, *FLAGS, *extra, *per_nl, f"-DSDPB_NL={nl}", "-c", os.path.join(CSRC, "solver_nl.hip"), "-o", obj])
     for src, name in ((os.path.join(CSRC, "capi.hip"), "capi.o"), (os.path.join(HERE, "hip_emu.cpp"), "hip_emu.o")):
         obj = os.path.join(OUT, name)

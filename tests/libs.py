@@ -17,7 +17,7 @@ def product_lib() -> str:
     return build.LIB if os.path.exists(build.LIB) else build.build()
 
 
-def emu_lib(panel=None) -> str:
+def emu_lib(panel=None, variant=None) -> str:
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
-    return build_emu.build(panel=panel)
+    return build_emu.build(panel=panel, variant=variant)

@@ -78,6 +78,27 @@ def test_emulated_syrk_Q_stage_and_saturated_columns(precision):
     s.close()
 
 
+def test_documented_build_without_toom4_keeps_working():
+    """-DSDPB_SYRK_NO_TOOM4 (the two-level Karatsuba image at 512 bits, 505 instead of 495
+    fraction bits at 3/4 of the speed) is an option a maintainer is told about: the exact product and the Q stage on
+    that build (round-3 advisor: keep the fallback covered)."""
+    import random
+    from oracle.oracle import Oracle
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, 512, lib_path=libs.emu_lib(variant="notoom4"))
+    assert s.limbs == 18 and s.fx_frac_bits == 32 * 16 - 7
+    o = Oracle(sdp, 512)
+    rng = random.Random(11)
+    rows, cols, fb = 37, 18, s.fx_frac_bits
+    vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
+    vals[3], vals[4], vals[5] = 2 ** fb - 1, -(2 ** fb) + 1, 0
+    got, want = s.op_int_syrk(rows, cols, vals), o.int_syrk(rows, cols, vals)
+    assert all(got[i + j * cols] == want[j + i * cols] for j in range(cols) for i in range(j, cols))
+    assert parity.check_syrk_Q(s, 512) <= -(512 - 40)
+    s.close()
+    o.close()
+
+
 def test_emulated_config_C1_at_its_stated_precision_128():
     """Whole iterations at 6 limbs (the narrowest compiled width) on the shipped SDP of BASELINE.json's
     first config; the GPU twin is tests/test_gpu_parity.py::test_config_C1_at_its_stated_precision_128."""

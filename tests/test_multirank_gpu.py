@@ -32,6 +32,14 @@ def _free_port():
 
 def _load(case):
     """-> (sdp, precision, params, block_source or None, golden iterations or None)"""
+    if case.startswith("C5J"):
+        # C5 (m = 6, two sample points, N = 2048, 1024 bits) with J blocks and the FULL N: "C5J4096" is half of C5, what four
+        # ranks of an 8-rank job hold together (profiles/tools/c5_half_multirank.py)
+        from sdpb_amd import synthetic
+        J = int(case[3:])
+        c = synthetic.config("C5")
+        sdp, src = synthetic.make_lazy([6] * J, [2] * J, c["N"], c["precision"], c["seed"])
+        return sdp, c["precision"], dict(parity.DEFAULT_PARAMS), src, None
     if case.startswith("C"):
         from sdpb_amd import synthetic
         name, _, scale = case.partition("x")
