@@ -116,7 +116,22 @@ def run_ranks(world, case, n_iter, timeout=900, gpu=True, env=None, emu_panel=No
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, n_iter, q, gpu, env, emu_panel, transport)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=timeout) for _ in procs)
+    # collect the records; a rank that dies (an exception in the worker, a device out of memory) ends the wait at once
+    # instead of leaving the others in a collective until the timeout
+    import queue as _queue
+    import time as _time
+    results, deadline = [], _time.time() + timeout
+    while len(results) < world:
+        try:
+            results.append(q.get(timeout=2.0))
+        except _queue.Empty:
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            if dead or _time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"ranks died (rank, exit code): {dead}" if dead else f"no result within {timeout} s")
+    results.sort()
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
