@@ -611,9 +611,10 @@ def main():
         achieved = k_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         # which instantiation that is: two Karatsuba levels keep 7 spare bits in the image, one level 3
         fb = solver.fx_frac_bits
-        fx = next(f for f in range(solver.limbs - 2, solver.limbs + 1) if 32 * f - fb in (17, 7, 3))   # limbs of the image (kernels.hpp: fx_limbs)
+        fx = next(f for f in range(solver.limbs - 2, solver.limbs + 1) if 32 * f - fb in (25, 17, 7, 3))   # limbs of the image (kernels.hpp: fx_limbs)
         rbg = 16 if fx >= 32 else 32   # rows per pass (solver.hpp: SDPB_SYRK2_RBG)
-        k_name = (f"k_syrk_fx2<{fx},{rbg},toom4> (+k_syrk4_finish)" if 32 * fx - 17 == fb else
+        k_name = (f"k_syrk_fx3<{fx},{rbg}> (Toom-4 x Karatsuba, +k_syrk4_finish)" if 32 * fx - 25 == fb else
+                  f"k_syrk_fx2<{fx},{rbg},toom4> (+k_syrk4_finish)" if 32 * fx - 17 == fb else
                   f"k_syrk_fx2<{fx},{rbg}> (+k_syrk_reduce)" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}> (+k_syrk_reduce)")
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_k_syrk_fx.json")

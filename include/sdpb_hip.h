@@ -142,10 +142,10 @@ int sdpb_hip_block_owner(sdpb_hip_ctx *ctx, int j);
 int sdpb_hip_limbs(sdpb_hip_ctx *ctx);
 /* Fraction bits FB of the fixed-point image of the normalised P' that the exact integer
  * Q' = P'^T P' is formed from (the reference keeps El::gmp::Precision() bits,
- * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here FB = 32 FX - 17 from --precision 400 up (Toom-4
- * image; FX = limbs - 2 rounded up to a multiple of four: 495 bits at 400 and at 512, 751 at 768, 1007 at
- * 1024) and 32 (limbs-2) - 7 at 128 and 256 bits (two Karatsuba levels)): inputs of sdpb_hip_op_int_syrk
- * obey |v| < 2^FB. */
+ * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here, with FX = limbs - 2 rounded up to a multiple of
+ * four, FB = 32 FX - 25 at --precision 400 ... 512 (FX = 16, Toom-4 x Karatsuba image: 487 bits),
+ * 32 FX - 17 above (Toom-4 image: 751 bits at 768, 1007 at 1024) and 32 (limbs-2) - 7 at 128 and 256 bits
+ * (two Karatsuba levels)): inputs of sdpb_hip_op_int_syrk obey |v| < 2^FB. */
 int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx);
 /* Measurement aid (bench/profiling only, never on the solve path): average HIP-event time in
  * ms of `reps` launches of one kernel of the iteration on synthetic device-resident operands.

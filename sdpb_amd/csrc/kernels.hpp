@@ -1858,8 +1858,37 @@ template <int FX> constexpr bool fx_toom4()
   return FX % 4 == 0 && FX >= 16 && FX <= SDPB_TOOM4_MAX_FX; // 512 bits and up: below, 17 bits are too large a share of the image
 #endif
 }
-template <int FX> constexpr int fx_planes() { return fx_toom4<FX>() ? 7 * (FX / 4) : fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2); }
-template <int FX> constexpr int fx_frac_bits() { return fx_toom4<FX>() ? 32 * FX - 17 : fx_two_level<FX>() ? 32 * FX - 7 : 32 * FX - 3; }
+// TOOM-4 x KARATSUBA (fx_toom4k<FX>(): FX = 16, i.e. --precision 400 ... 512): each of the seven evaluated pieces
+// e < 2^(32 M2 - 2) is split once more, e = e_lo + e_hi 2^H with halves of H = 16 M2 - 1 bits and e_mid = e_lo + e_hi
+// < 2^(16 M2), so a row pair costs 21 products of M3 x M3 limbs (M3 = FX/8): 84 limb products at FX = 16 instead of the
+// 112 of Toom-4 alone.  The two spare bits per evaluated piece come out of the piece width: w = 32 M2 - 6, hence
+// FB = 4 w - 1 = 32 FX - 25 (487 fraction bits at --precision 512).  Image: 21 M3-limb pieces per element, piece-major,
+// group 3 g + u with g the Toom-4 group above and u in (lo, hi, mid); k_syrk_fx3 recombines the three sums of a
+// Toom-4 group in registers (e e' = lo lo' + (mid mid' - lo lo' - hi hi') 2^H + hi hi' 2^(2H)) and writes what
+// k_syrk_fx2<.., true> writes, so k_syrk4_finish and everything after it are shared.
+template <int FX> constexpr bool fx_toom4k()
+{
+#if defined(SDPB_SYRK_NO_TOOM4K)
+  return false;
+#else
+  return fx_toom4<FX>() && FX == 16;
+#endif
+}
+// bits per Toom-4 piece
+template <int FX> constexpr int toom_wb() { return 32 * (FX / 4) - (fx_toom4k<FX>() ? 6 : 4); }
+template <int FX> constexpr int fx_planes()
+{
+  return fx_toom4k<FX>() ? 21 * (FX / 8) : fx_toom4<FX>() ? 7 * (FX / 4) : fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2);
+}
+template <int FX> constexpr int fx_frac_bits() { return fx_toom4<FX>() ? 4 * toom_wb<FX>() - 1 : fx_two_level<FX>() ? 32 * FX - 7 : 32 * FX - 3; }
+// elements per group plane of the image of a rows x cols operand: k_syrk_fx3 stages whole blocks of `rb` rows and
+// whole 32-column tiles without bounds checks, so its image is padded (the pad is zeroed once, when the image is allocated)
+template <int FX> constexpr size_t fx_image_stride(size_t rows, size_t cols, int rb)
+{
+  return fx_toom4k<FX>() ? (rows + rb - 1) / rb * rb * cols + 64 : rows * cols;
+}
+// edge of the output tiles of the syrk kernel in use: k_syrk_fx3 gives a lane 2 x 2 outputs
+template <int FX> constexpr int syrk_tile_edge() { return fx_toom4k<FX>() ? 32 : 16; }
 
 // out = (x >> BIT0) mod 2^NB as OUT limbs (compile-time positions)
 template <int BIT0, int NB, int W, int OUT> MW_HD void bits_slice(const uint32_t (&x)[W], uint32_t (&out)[OUT])
@@ -2011,6 +2040,78 @@ template <int FX> MW_HD void fx_store2(const uint32_t (&mag)[FX], bool negative,
     }
 }
 
+// one M2-limb piece with the widest loads its size allows (pieces are M2*4-byte aligned)
+struct alignas(16) PieceQuad
+{
+  uint32_t w[4];
+};
+struct alignas(8) PiecePair
+{
+  uint32_t w[2];
+};
+template <int M2> MW_HD void piece_load(const uint32_t *p, uint32_t (&x)[M2])
+{
+  if constexpr(M2 % 4 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 4; ++q)
+        {
+          const PieceQuad v = *reinterpret_cast<const PieceQuad *>(p + 4 * q);
+#pragma unroll
+          for(int l = 0; l < 4; ++l)
+            x[4 * q + l] = v.w[l];
+        }
+    }
+  else if constexpr(M2 % 2 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 2; ++q)
+        {
+          const PiecePair v = *reinterpret_cast<const PiecePair *>(p + 2 * q);
+          x[2 * q] = v.w[0];
+          x[2 * q + 1] = v.w[1];
+        }
+    }
+  else
+    {
+#pragma unroll
+      for(int l = 0; l < M2; ++l)
+        x[l] = p[l];
+    }
+}
+template <int M2> MW_HD void piece_store(uint32_t *p, const uint32_t (&x)[M2])
+{
+  if constexpr(M2 % 4 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 4; ++q)
+        {
+          PieceQuad v;
+#pragma unroll
+          for(int l = 0; l < 4; ++l)
+            v.w[l] = x[4 * q + l];
+          *reinterpret_cast<PieceQuad *>(p + 4 * q) = v;
+        }
+    }
+  else if constexpr(M2 % 2 == 0)
+    {
+#pragma unroll
+      for(int q = 0; q < M2 / 2; ++q)
+        {
+          PiecePair v;
+          v.w[0] = x[2 * q];
+          v.w[1] = x[2 * q + 1];
+          *reinterpret_cast<PiecePair *>(p + 2 * q) = v;
+        }
+    }
+  else
+    {
+#pragma unroll
+      for(int l = 0; l < M2; ++l)
+        p[l] = x[l];
+    }
+}
+
 // ---- Toom-4 image and the signed multi-limb helpers of its interpolation ------------------
 // out = sum_k c_k p_k for small non-negative c_k (no overflow by construction: < 2^(32 M2))
 template <int M2> MW_HD void toom_lin(uint32_t (&out)[M2], const uint32_t (&p)[4][M2], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
@@ -2028,8 +2129,10 @@ template <int M2> MW_HD void toom_lin(uint32_t (&out)[M2], const uint32_t (&p)[4
 // seven-piece image of one element (|v| < 2^FB, FB = 32 FX - 17)
 template <int FX> MW_HD void fx_store4(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
 {
-  constexpr int M2 = FX / 4, WB = 32 * M2 - 4, FB = fx_frac_bits<FX>();
+  constexpr int M2 = FX / 4, WB = toom_wb<FX>(), FB = fx_frac_bits<FX>();
+  constexpr int TOPBIT = WB - 32 * (M2 - 1); // bit of b = 2^WB inside the top limb of a piece
   static_assert(FB == 4 * WB - 1 && FB / 32 == FX - 1, "a' = v + 2^FB fills four pieces of WB bits");
+  static_assert(TOPBIT >= 0 && TOPBIT + 4 <= 32, "15 b fits the top limb");
   uint32_t a[FX];
   uint64_t borrow = 0;
 #pragma unroll
@@ -2065,7 +2168,7 @@ template <int FX> MW_HD void fx_store4(const uint32_t (&mag)[FX], bool negative,
     uint32_t pos[M2], neg[M2];
     toom_lin<M2>(pos, p, 1, 0, 1, 0);
     toom_lin<M2>(neg, p, 0, 1, 0, 1);
-    pos[M2 - 1] += 2u << 28; // 2 b = 2^(WB+1): bit 29 of the top limb
+    pos[M2 - 1] += 2u << TOPBIT; // 2 b = 2^(WB+1)
     uint64_t bw = 0;
 #pragma unroll
     for(int i = 0; i < M2; ++i)
@@ -2076,7 +2179,7 @@ template <int FX> MW_HD void fx_store4(const uint32_t (&mag)[FX], bool negative,
       }
     toom_lin<M2>(pos, p, 1, 0, 4, 0);
     toom_lin<M2>(neg, p, 0, 2, 0, 8);
-    pos[M2 - 1] += 10u << 28; // 10 b
+    pos[M2 - 1] += 10u << TOPBIT; // 10 b
     bw = 0;
 #pragma unroll
     for(int i = 0; i < M2; ++i)
@@ -2086,13 +2189,65 @@ template <int FX> MW_HD void fx_store4(const uint32_t (&mag)[FX], bool negative,
         bw = (t >> 63) & 1u;
       }
   }
-#pragma unroll
-  for(int g = 0; g < 7; ++g)
+  if constexpr(fx_toom4k<FX>())
     {
-      uint32_t *o = fx + ((size_t)g * fx_stride + idx) * M2;
+      // every e[g] < 15 b < 2^(32 M2 - 2): halves of H = 16 M2 - 1 bits and their sum, M3 limbs each
+      constexpr int M3 = FX / 8, H = 16 * M2 - 1;
+#pragma unroll
+      for(int g = 0; g < 7; ++g)
+        {
+          uint32_t lo[M3], hi[M3], mid[M3];
+          bits_slice<0, H>(e[g], lo);
+          bits_slice<H, H>(e[g], hi);
+          uint64_t cy = 0;
+#pragma unroll
+          for(int i = 0; i < M3; ++i)
+            {
+              const uint64_t t = (uint64_t)lo[i] + hi[i] + cy;
+              mid[i] = (uint32_t)t;
+              cy = t >> 32;
+            }
+          piece_store<M3>(fx + ((size_t)(3 * g + 0) * fx_stride + idx) * M3, lo);
+          piece_store<M3>(fx + ((size_t)(3 * g + 1) * fx_stride + idx) * M3, hi);
+          piece_store<M3>(fx + ((size_t)(3 * g + 2) * fx_stride + idx) * M3, mid);
+        }
+    }
+  else
+    {
+#pragma unroll
+      for(int g = 0; g < 7; ++g)
+        {
+          uint32_t *o = fx + ((size_t)g * fx_stride + idx) * M2;
+#pragma unroll
+          for(int i = 0; i < M2; ++i)
+            o[i] = e[g][i];
+        }
+    }
+}
+// the M2-limb evaluated piece of Toom-4 group g of element e (either image)
+template <int FX> MW_HD void toom_piece_load(const uint32_t *fx, size_t fx_stride, int g, size_t e, uint32_t (&x)[FX / 4])
+{
+  constexpr int M2 = FX / 4;
+  if constexpr(fx_toom4k<FX>())
+    {
+      constexpr int M3 = FX / 8, H = 16 * M2 - 1;
+      uint32_t lo[M2], lo3[M3], hi[M3];
+      piece_load<M3>(fx + ((size_t)(3 * g + 0) * fx_stride + e) * M3, lo3);
+      piece_load<M3>(fx + ((size_t)(3 * g + 1) * fx_stride + e) * M3, hi);
 #pragma unroll
       for(int i = 0; i < M2; ++i)
-        o[i] = e[g][i];
+        lo[i] = i < M3 ? lo3[i < M3 ? i : 0] : 0u;
+      add_shifted<M2, M3>(lo, hi, H, false);
+#pragma unroll
+      for(int i = 0; i < M2; ++i)
+        x[i] = lo[i];
+    }
+  else
+    {
+      const uint32_t *src = fx + ((size_t)g * fx_stride + e) * M2;
+#pragma unroll
+      for(int i = 0; i < M2; ++i)
+        x[i] = src[i];
     }
 }
 // Z-limb two's-complement integers (Z = 2 M2 + 2: a sum over < 2^32 rows of products of two
@@ -2405,12 +2560,13 @@ __global__ void __launch_bounds__(WG) k_fx_colsum_final(const uint32_t *partial,
 // (8x8 tiles) so that consecutive entries share operand panels.
 // split_tile > 0: the tiles of the columns left of tile column `split_tile` come first (super-block order inside
 // each group), *count_left = how many they are -- the two launches of the chunked Q' take the two halves of the list
-inline std::vector<uint32_t> syrk_tile_order(int N, int split_tile = 0, int *count_left = nullptr)
+// edge: 16, or 32 for k_syrk_fx3 (super-blocks of 4x4 tiles then cover the same 128 columns)
+inline std::vector<uint32_t> syrk_tile_order(int N, int split_tile = 0, int *count_left = nullptr, int edge = 16)
 {
-  int SB = 8;
+  int SB = edge == 16 ? 8 : 4;
   if(const char *env = std::getenv("SDPB_HIP_SYRK_SB")) // tuning knob: super-block edge in tiles
     SB = std::max(1, std::atoi(env));
-  const int tiles = (N + 15) / 16, nsb = (tiles + SB - 1) / SB;
+  const int tiles = (N + edge - 1) / edge, nsb = (tiles + SB - 1) / SB;
   std::vector<uint32_t> out;
   for(int bi = 0; bi < nsb; ++bi)
     for(int bj = 0; bj <= bi; ++bj)
@@ -2750,7 +2906,11 @@ __global__ void __launch_bounds__(WG) k_fx_colsum2(const uint32_t *fx, size_t fx
         for(int u = 0; u < 4; ++u)
           {
             const int grp = TOOM ? (u == 0 ? 0 : u == 1 ? 1 : u == 2 ? 3 : 6) : (u < 2 ? u : u + 1);
-            const uint32_t *src = fx + ((size_t)grp * fx_stride + e) * M2;
+            uint32_t src[M2];
+            if constexpr(TOOM)
+              toom_piece_load<FX>(fx, fx_stride, grp, e, src);
+            else
+              piece_load<M2>(fx + ((size_t)grp * fx_stride + e) * M2, src);
             uint64_t cy = 0;
 #pragma unroll
             for(int k = 0; k < A; ++k)
@@ -2843,7 +3003,7 @@ template <int FX>
 __global__ void __launch_bounds__(WG)
   k_fx_colsum4_final(const uint32_t *partial, int nslices, int N, uint32_t *acc, size_t acc_stride, uint32_t *toomU, unsigned long long nrows_local)
 {
-  constexpr int M2 = FX / 4, A = M2 + 2, W = 2 * FX + 2, WB = 32 * M2 - 4, Z = 2 * M2 + 2;
+  constexpr int M2 = FX / 4, A = M2 + 2, W = 2 * FX + 2, WB = toom_wb<FX>(), Z = 2 * M2 + 2;
   const int col = blockIdx.x * WG + threadIdx.x;
   if(col >= N)
     return;
@@ -2947,7 +3107,7 @@ template <int FX>
 __global__ void __launch_bounds__(WG)
   k_syrk4_finish(const uint32_t *part, int nsplit, const uint32_t *toomU, uint32_t *acc, size_t acc_stride, int N, size_t idx0, size_t idx1)
 {
-  constexpr int M2 = FX / 4, A2 = 2 * M2 + 1, Z = 2 * M2 + 2, W = 2 * FX + 2, WB = 32 * M2 - 4;
+  constexpr int M2 = FX / 4, A2 = 2 * M2 + 1, Z = 2 * M2 + 2, W = 2 * FX + 2, WB = toom_wb<FX>();
   const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
   if(idx >= idx1)
     return;
@@ -3001,78 +3161,6 @@ __global__ void __launch_bounds__(WG)
 #pragma unroll
   for(int k = 0; k < W; ++k)
     acc[(size_t)k * acc_stride + idx] = g[k];
-}
-
-// one M2-limb piece with the widest loads its size allows (pieces are M2*4-byte aligned)
-struct alignas(16) PieceQuad
-{
-  uint32_t w[4];
-};
-struct alignas(8) PiecePair
-{
-  uint32_t w[2];
-};
-template <int M2> MW_HD void piece_load(const uint32_t *p, uint32_t (&x)[M2])
-{
-  if constexpr(M2 % 4 == 0)
-    {
-#pragma unroll
-      for(int q = 0; q < M2 / 4; ++q)
-        {
-          const PieceQuad v = *reinterpret_cast<const PieceQuad *>(p + 4 * q);
-#pragma unroll
-          for(int l = 0; l < 4; ++l)
-            x[4 * q + l] = v.w[l];
-        }
-    }
-  else if constexpr(M2 % 2 == 0)
-    {
-#pragma unroll
-      for(int q = 0; q < M2 / 2; ++q)
-        {
-          const PiecePair v = *reinterpret_cast<const PiecePair *>(p + 2 * q);
-          x[2 * q] = v.w[0];
-          x[2 * q + 1] = v.w[1];
-        }
-    }
-  else
-    {
-#pragma unroll
-      for(int l = 0; l < M2; ++l)
-        x[l] = p[l];
-    }
-}
-template <int M2> MW_HD void piece_store(uint32_t *p, const uint32_t (&x)[M2])
-{
-  if constexpr(M2 % 4 == 0)
-    {
-#pragma unroll
-      for(int q = 0; q < M2 / 4; ++q)
-        {
-          PieceQuad v;
-#pragma unroll
-          for(int l = 0; l < 4; ++l)
-            v.w[l] = x[4 * q + l];
-          *reinterpret_cast<PieceQuad *>(p + 4 * q) = v;
-        }
-    }
-  else if constexpr(M2 % 2 == 0)
-    {
-#pragma unroll
-      for(int q = 0; q < M2 / 2; ++q)
-        {
-          PiecePair v;
-          v.w[0] = x[2 * q];
-          v.w[1] = x[2 * q + 1];
-          *reinterpret_cast<PiecePair *>(p + 2 * q) = v;
-        }
-    }
-  else
-    {
-#pragma unroll
-      for(int l = 0; l < M2; ++l)
-        p[l] = x[l];
-    }
 }
 
 // d -= x (both A limbs, d >= x)
@@ -3331,6 +3419,264 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
         acc[(size_t)k * acc_stride + o] = w[k];
     }
   }
+}
+
+// The Toom-4 x Karatsuba product (fx_toom4k<FX>()): acc as k_syrk_fx2<FX, RBG, true> leaves it -- the seven sums
+// sum_r e_g(r,i) e_g(r,j), A2 limbs each, per row split -- from the 21-group image of M3-limb pieces.
+// A workgroup owns a 32 x 32 tile, a lane 2 x 2 outputs: i in {i0, i0 + 16}, j in {j0, j0 + 16} with i0 = 32 ti + li,
+// j0 = 32 tj + lj, so per staged row it reads two pieces of each operand (8 B each at M3 = 2: the i pieces
+// conflict-free, the j pieces a broadcast) for four M3 x M3 products -- the same 16 MAC pairs per 32 B of LDS reads
+// as the 4 x 4-limb product of k_syrk_fx2, and the same staging: 16-byte global_load_lds of a PAIR of adjacent
+// columns' pieces, [row][column][M3 limbs] in LDS.  Quadrants of the tile that hold no output (above the diagonal of
+// a diagonal tile, past column N) are skipped workgroup-wide, so the executed products are those of the 16 x 16
+// tiling.  One SWEEP over the split's rows = one of the 21 products: a pass per block of RBG rows, the column
+// accumulators (96 bits each, 4 x 3 per lane) live in registers for the whole sweep and are folded when it ends; the
+// three sums of a Toom-4 group are recombined after its third sweep.
+template <int FX, int RBG>
+__global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
+  k_syrk_fx3(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
+             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, int gsplit)
+{
+  // gsplit = 7: a workgroup takes ONE Toom-4 group of its (tile, row split) instead of all seven (the sweeps are
+  // independent): seven times the workgroups where the output has few tiles, and a shorter tail everywhere
+  constexpr int M2 = FX / 4, M3 = FX / 8, A3 = 2 * M3 + 1, A2 = 2 * M2 + 1, H = 16 * M2 - 1;
+  static_assert(M3 == 2, "a pair of pieces is one 16-byte load");
+  constexpr int NPAIR = RBG * 16, GL = NPAIR / WG; // 16-byte pairs per operand per pass, per lane
+  static_assert(NPAIR % WG == 0, "a pass stages a whole number of pairs per lane");
+  const uint32_t *fx = (const uint32_t *)__builtin_assume_aligned(fx_in, 8);
+  const int nitem = ntile * nsplit * gsplit, per = (nitem + 7) / 8;
+  const int item = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+  if((int)(blockIdx.x / 8) >= per || item >= nitem)
+    return;
+  // items that follow each other share the rows and the group, i.e. the operand panels of neighbouring tiles
+  const int sg = item / ntile, tile = item % ntile, split = sg / gsplit;
+  const int grp_begin = (sg % gsplit) * (7 / gsplit), grp_end = grp_begin + 7 / gsplit;
+  const unsigned row_begin = (unsigned)split * rows_per_split;
+  const unsigned row_end = (row_begin + rows_per_split < nrows && split + 1 < nsplit) ? row_begin + rows_per_split : nrows;
+  acc += (size_t)split * 7 * A2 * acc_stride;
+  const uint32_t tt = tile_list[tile];
+  const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
+  const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
+  const int i0 = ti * 32 + li, j0 = tj * 32 + lj;
+  // quadrant (p, q): rows i0 + 16 p of the output against columns j0 + 16 q; workgroup-uniform
+  const bool half_i = ti * 32 + 16 < N, half_j = tj * 32 + 16 < N;
+  const int mask = 1 | (half_i ? 2 : 0) | ((half_j && tj < ti) ? 4 : 0) | ((half_i && half_j) ? 8 : 0); // bit p + 2 q
+  __shared__ __attribute__((aligned(16))) uint32_t sa[2 * NPAIR * 4];
+  __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NPAIR * 4];
+  uint64_t cc[4][2 * M3 - 1];
+  uint32_t hh[4][2 * M3 - 1];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK2_NO_GLDS)
+  constexpr bool DIRECT = true;
+#else
+  constexpr bool DIRECT = false;
+#endif
+  // Staging of the NEXT pass: the image is padded with zero rows to a multiple of RBG and every row block a workgroup
+  // touches lies inside it (fx3_image_stride), so a pass is the same per-lane offsets from a workgroup-uniform base:
+  // no per-lane pointer selects.  Columns past N load whatever follows the row (the pad behind the last one): they
+  // only reach outputs that are not stored.
+  uint32_t va[DIRECT ? 1 : GL][4], vb[DIRECT ? 1 : GL][4];
+  uint32_t offa[GL], offb[GL];
+#pragma unroll
+  for(int t = 0; t < GL; ++t)
+    {
+      const int e = threadIdx.x + t * WG;
+      const int col = e & 15, rr = e >> 4;
+      offa[t] = (uint32_t)(((size_t)rr * N + ti * 32 + 2 * col) * M3);
+      offb[t] = (uint32_t)(((size_t)rr * N + tj * 32 + 2 * col) * M3);
+    }
+  auto fetch = [&](int g, unsigned r0, int into) __attribute__((always_inline)) {
+    const uint32_t *base = fx + ((size_t)g * fx_stride + (size_t)r0 * (size_t)N) * M3;
+#pragma unroll
+    for(int t = 0; t < GL; ++t)
+      {
+        if constexpr(DIRECT)
+          {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int wbase = (into * NPAIR + t * WG + (int)(threadIdx.x & ~63u)) * 4; // this wavefront's 64 pairs
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + offa[t]),
+                                             (__attribute__((address_space(3))) void *)(sa + wbase), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + offb[t]),
+                                             (__attribute__((address_space(3))) void *)(sb + wbase), 16, 0, 0);
+#endif
+          }
+        else
+          {
+#pragma unroll
+            for(int l = 0; l < 4; ++l)
+              {
+                va[t][l] = base[offa[t] + l];
+                vb[t][l] = base[offb[t] + l];
+              }
+          }
+      }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+    if constexpr(!DIRECT)
+      {
+#pragma unroll
+        for(int t = 0; t < GL; ++t)
+          {
+            const int e = threadIdx.x + t * WG;
+            piece_store<4>(sa + (buf * NPAIR + e) * 4, va[t]);
+            piece_store<4>(sb + (buf * NPAIR + e) * 4, vb[t]);
+          }
+      }
+  };
+  // the RBG staged rows of one pass for the quadrants of MASK: the column accumulators c + h 2^64 (96 bits: a sweep has
+  // fewer than 2^31 rows) persist over the whole sweep and are folded once, when it ends
+  auto rows = [&](auto mask_c, int buf, uint64_t (&c)[4][2 * M3 - 1], uint32_t (&h)[4][2 * M3 - 1]) __attribute__((always_inline)) {
+    constexpr int MASK = decltype(mask_c)::value;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK3_NO_ASM)
+    // LDS reads and MACs as a few large asm statements per row (every asm statement costs a wait state), and the
+    // reads invisible to the compiler's wait-count pass, which would otherwise drain the global_load_lds of the NEXT
+    // pass (vmcnt(0)) before the first read of this one -- those land in the other buffer; the barrier that ends the
+    // pass waits for them
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(sa + buf * NPAIR * 4 + li * M3);
+    const uint32_t lb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(sb + buf * NPAIR * 4 + lj * M3);
+#define FX3_P(C, H, X, Y) "v_mad_u64_u32 %" #C ", vcc, %" #X ", %" #Y ", %" #C "\n\tv_addc_co_u32 %" #H ", vcc, 0, %" #H ", vcc\n\t"
+#define FX3_MAC_BOTH(o0, o1, a0x, a0y, a1x, a1y, bx, by)                                                                                   \
+  asm volatile(FX3_P(0, 6, 12, 16) FX3_P(3, 9, 14, 16) FX3_P(1, 7, 12, 17) FX3_P(4, 10, 14, 17) FX3_P(1, 7, 13, 16) FX3_P(4, 10, 15, 16)   \
+                 FX3_P(2, 8, 13, 17) FX3_P(5, 11, 15, 17)                                                                                  \
+               : "+v"(c[o0][0]), "+v"(c[o0][1]), "+v"(c[o0][2]), "+v"(c[o1][0]), "+v"(c[o1][1]), "+v"(c[o1][2]), "+v"(h[o0][0]),           \
+                 "+v"(h[o0][1]), "+v"(h[o0][2]), "+v"(h[o1][0]), "+v"(h[o1][1]), "+v"(h[o1][2])                                            \
+               : "v"(a0x), "v"(a0y), "v"(a1x), "v"(a1y), "v"(bx), "v"(by)                                                                  \
+               : "vcc")
+#define FX3_MAC_ONE(o0, ax, ay, bx, by)                                                                                                    \
+  asm volatile(FX3_P(0, 3, 6, 8) FX3_P(1, 4, 6, 9) FX3_P(1, 4, 7, 8) FX3_P(2, 5, 7, 9)                                                     \
+               : "+v"(c[o0][0]), "+v"(c[o0][1]), "+v"(c[o0][2]), "+v"(h[o0][0]), "+v"(h[o0][1]), "+v"(h[o0][2])                            \
+               : "v"(ax), "v"(ay), "v"(bx), "v"(by)                                                                                        \
+               : "vcc")
+#define FX3_ROW(O0, O1)                                                                                                                    \
+  {                                                                                                                                        \
+    u32x4 va, vb; /* both pieces of either operand, also where MASK needs one (their columns are staged all the same) */                   \
+    asm volatile("ds_read2_b64 %0, %2 offset0:" #O0 " offset1:" #O1 "\n\tds_read2_b64 %1, %3 offset0:" #O0 " offset1:" #O1                \
+                 "\n\ts_waitcnt lgkmcnt(0)"                                                                                                \
+                 : "=&v"(va), "=&v"(vb)                                                                                                    \
+                 : "v"(xa), "v"(xb)                                                                                                        \
+                 : "memory");                                                                                                              \
+    if constexpr(MASK == 15)                                                                                                               \
+      {                                                                                                                                    \
+        FX3_MAC_BOTH(0, 1, va.x, va.y, va.z, va.w, vb.x, vb.y);                                                                            \
+        FX3_MAC_BOTH(2, 3, va.x, va.y, va.z, va.w, vb.z, vb.w);                                                                            \
+      }                                                                                                                                    \
+    else if constexpr(MASK == 11)                                                                                                          \
+      {                                                                                                                                    \
+        FX3_MAC_BOTH(0, 1, va.x, va.y, va.z, va.w, vb.x, vb.y);                                                                            \
+        FX3_MAC_ONE(3, va.z, va.w, vb.z, vb.w);                                                                                            \
+      }                                                                                                                                    \
+    else if constexpr(MASK == 5)                                                                                                           \
+      {                                                                                                                                    \
+        FX3_MAC_ONE(0, va.x, va.y, vb.x, vb.y);                                                                                            \
+        FX3_MAC_ONE(2, va.x, va.y, vb.z, vb.w);                                                                                            \
+      }                                                                                                                                    \
+    else                                                                                                                                   \
+      FX3_MAC_ONE(0, va.x, va.y, vb.x, vb.y);                                                                                              \
+  }
+    static_assert(RBG % 4 == 0 && M3 == 2, "four rows per trip, offsets in units of 8 bytes");
+#pragma unroll 1
+    for(int rr = 0; rr < RBG; rr += 4)
+      {
+        const uint32_t xa = la + rr * 256, xb = lb + rr * 256; // a staged row is 64 words
+        FX3_ROW(0, 16)
+        FX3_ROW(32, 48)
+        FX3_ROW(64, 80)
+        FX3_ROW(96, 112)
+      }
+#undef FX3_ROW
+#undef FX3_MAC_ONE
+#undef FX3_MAC_BOTH
+#undef FX3_P
+#else
+    // column x of the tile sits at word 2 x of a staged row: the lane's two pieces are 16 columns = 32 words apart
+    const uint32_t *pa = sa + buf * NPAIR * 4 + li * M3, *pb = sb + buf * NPAIR * 4 + lj * M3;
+#pragma unroll SDPB_SYRK2_UNROLL
+    for(int rr = 0; rr < RBG; ++rr)
+      {
+        uint32_t a0[M3], a1[M3], b0[M3], b1[M3];
+        piece_load<M3>(pa + rr * 64, a0);
+        piece_load<M3>(pb + rr * 64, b0);
+        if constexpr((MASK & 10) != 0)
+          piece_load<M3>(pa + rr * 64 + 32, a1);
+        if constexpr((MASK & 12) != 0)
+          piece_load<M3>(pb + rr * 64 + 32, b1);
+        SyrkColumns<M3, 0>::run(a0, b0, c[0], h[0]);
+        if constexpr((MASK & 2) != 0)
+          SyrkColumns<M3, 0>::run(a1, b0, c[1], h[1]);
+        if constexpr((MASK & 4) != 0)
+          SyrkColumns<M3, 0>::run(a0, b1, c[2], h[2]);
+        if constexpr((MASK & 8) != 0)
+          SyrkColumns<M3, 0>::run(a1, b1, c[3], h[3]);
+      }
+#endif
+  };
+  // One sweep over the split's rows per product (group, u): 36 accumulator registers live in the row loop instead of
+  // the 108 of three products at once; the three folded sums of a group (A3 limbs per output) wait for its last sweep.
+  for(int grp = grp_begin; grp < grp_end; ++grp)
+    {
+      uint32_t g3[3][4][A3];
+#pragma unroll
+      for(int u = 0; u < 3; ++u)
+        {
+#pragma unroll
+          for(int o = 0; o < 4; ++o)
+#pragma unroll
+            for(int k = 0; k < 2 * M3 - 1; ++k)
+              {
+                cc[o][k] = 0;
+                hh[o][k] = 0;
+              }
+          if(grp > grp_begin || u > 0)
+            __syncthreads(); // every wavefront has left the last pass of the previous sweep
+          fetch(3 * grp + u, row_begin, 0);
+          store(0);
+          __syncthreads();
+          int buf = 0;
+          for(unsigned r0 = row_begin; r0 < row_end; r0 += RBG)
+            {
+              // (after the last block of the sweep: a block that exists, staged and never read)
+              fetch(3 * grp + u, r0 + RBG < row_end ? r0 + RBG : row_begin, buf ^ 1);
+              switch(mask)
+                {
+                case 15: rows(std::integral_constant<int, 15>(), buf, cc, hh); break;
+                case 11: rows(std::integral_constant<int, 11>(), buf, cc, hh); break; // diagonal tile: quadrant (0, 1) lies above the diagonal
+                case 5: rows(std::integral_constant<int, 5>(), buf, cc, hh); break;   // last tile row, fewer than 17 of its 32 rows inside N
+                default: rows(std::integral_constant<int, 1>(), buf, cc, hh); break;  // ... and its diagonal tile
+                }
+              store(buf ^ 1);
+              __syncthreads();
+              buf ^= 1;
+            }
+#pragma unroll
+          for(int o = 0; o < 4; ++o)
+            {
+#pragma unroll
+              for(int k = 0; k < A3; ++k)
+                g3[u][o][k] = 0;
+              syrk_fold<M3, A3>(g3[u][o], cc[o], hh[o]);
+            }
+        }
+      // e e' = lo lo' + (mid mid' - lo lo' - hi hi') 2^H + hi hi' 2^(2H)
+#pragma unroll
+      for(int o = 0; o < 4; ++o)
+        {
+          const int i = i0 + 16 * (o & 1), j = j0 + 16 * (o >> 1);
+          if(!((mask >> o) & 1) || i >= N || j > i)
+            continue;
+          sub_limbs<A3>(g3[2][o], g3[0][o]);
+          sub_limbs<A3>(g3[2][o], g3[1][o]);
+          uint32_t w[A2];
+#pragma unroll
+          for(int k = 0; k < A2; ++k)
+            w[k] = k < A3 ? g3[0][o][k < A3 ? k : 0] : 0u;
+          add_shifted<A2, A3>(w, g3[2][o], H, false);
+          add_shifted<A2, A3>(w, g3[1][o], 2 * H, false);
+          const size_t at = (size_t)i + (size_t)j * N;
+#pragma unroll
+          for(int k = 0; k < A2; ++k)
+            acc[(size_t)(grp * A2 + k) * acc_stride + at] = w[k];
+        }
+    }
 }
 
 // Remove the bias in place (after any cross-GPU sum): for i >= j

@@ -246,6 +246,8 @@ template <int NL> class Solver : public SolverBase
   static_assert(FX <= NL, "the image is cut from an NL-limb product");
   static constexpr int ACCW = 2 * FX + 2;
   static constexpr bool SYRK_TOOM4 = fx_toom4<FX>();         // seven (FX/4)^2 products per row pair (k_syrk_fx2<.., true> + k_syrk4_finish)
+  static constexpr bool SYRK_TOOM4K = fx_toom4k<FX>();       // ... and one Karatsuba level below them: 21 (FX/8)^2 products (k_syrk_fx3)
+  static constexpr int SYRK_EDGE = syrk_tile_edge<FX>();     // output tile of the syrk kernel in use
   static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>() || SYRK_TOOM4; // piece-major image: nine (two Karatsuba levels) or seven pieces
   static constexpr int SYRK_PART_PLANES = SYRK_TOOM4 ? 7 * (2 * (FX / 4) + 1) : ACCW; // planes one row split writes
   // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
@@ -699,14 +701,14 @@ private:
     lam2_.alloc(std::max(2 * Jl_, 1), NL);
     ratio_.alloc((size_t)5 * std::max(Jl_, 1) + 1, NL);
     scal_.alloc(S_COUNT, NL);
-    fx_stride_ = off_bt ? off_bt : 1;
-    fx_.alloc(fx_stride_ * fx_planes<FX>());
+    fx_stride_ = image_stride((size_t)Ptot_, (size_t)N_);
+    image_alloc(fx_, fx_stride_);
     acc_stride_ = (size_t)N_ * N_ + N_; // N x N outputs + N column sums (k_fx_colsum)
     acc_.alloc(acc_stride_ * ACCW);
     {
       // partial outputs of the row-split syrk (sized once, here, not inside the iteration)
-      const unsigned tiles = cdiv(N_, 16);
-      const int nsplit = syrk_row_splits((int)(tiles * (tiles + 1) / 2), (unsigned)Ptot_, num_cus_ * syrk_waves_per_simd<FX>(), SYRK_RB);
+      const unsigned tiles = cdiv(N_, SYRK_EDGE);
+      const int nsplit = syrk_row_splits((int)(tiles * (tiles + 1) / 2) * syrk_group_split(), (unsigned)Ptot_, num_cus_ * syrk_waves_per_simd<FX>(), SYRK_RB);
       if(nsplit > 1 || SYRK_TOOM4)
         syrk_part_.alloc((size_t)nsplit * SYRK_PART_PLANES * acc_stride_);
       if(SYRK_TOOM4)
@@ -714,7 +716,7 @@ private:
     }
     colsum_slices_ = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv(Ptot_, 64)));
     colsum_partial_.alloc((size_t)colsum_slices_ * (FX + 8) * N_); // 2 (FX/2 + 2) or 4 (FX/4 + 2) limbs per column and slice
-    syrk_tiles_.upload(syrk_tile_order(N_));
+    syrk_tiles_.upload(syrk_tile_order(N_, 0, nullptr, SYRK_EDGE));
     if(world_ > 1)
       {
         acc64_.alloc(((size_t)N_ * (N_ + 1) / 2 + N_) * ACCW);
@@ -755,17 +757,19 @@ private:
       bool want = false;
       if(const char *e = std::getenv("SDPB_HIP_Q_CHASE"))
         want = std::atoi(e) != 0;
-      const unsigned tiles = cdiv(N_, 16);
+      const unsigned tiles = cdiv(N_, SYRK_EDGE);
       chase_ntile_ = (int)(tiles * (tiles + 1) / 2);
       chase_hA_ = std::max(step, (panels / 2) / step * step);
+      if((PB * chase_hA_) % SYRK_EDGE != 0) // the chunk boundary is a tile boundary
+        chase_hA_ += step;
       chase_cA_ = PB * chase_hA_;
       q_chase_ = want && !dist_cholq_ && !(overlap_syrk_ && world_ == 1) && chase_hA_ < panels && chase_cA_ < N_; // the same decision on every rank
       if(q_chase_)
         {
-          syrk_tiles_.upload(syrk_tile_order(N_, chase_cA_ / 16, &chase_ntileA_));
+          syrk_tiles_.upload(syrk_tile_order(N_, chase_cA_ / SYRK_EDGE, &chase_ntileA_, SYRK_EDGE));
           const int slots = num_cus_ * syrk_waves_per_simd<FX>();
-          const int ns = std::max(syrk_row_splits(chase_ntileA_, (unsigned)Ptot_, slots, SYRK_RB),
-                                  syrk_row_splits(chase_ntile_ - chase_ntileA_, (unsigned)Ptot_, slots, SYRK_RB));
+          const int ns = std::max(syrk_row_splits(chase_ntileA_ * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB),
+                                  syrk_row_splits((chase_ntile_ - chase_ntileA_) * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB));
           if((ns > 1 || SYRK_TOOM4) && syrk_part_.n < (size_t)ns * SYRK_PART_PLANES * acc_stride_)
             syrk_part_.alloc((size_t)ns * SYRK_PART_PLANES * acc_stride_);
         }
@@ -849,8 +853,8 @@ public:
     ss << (first ? "" : ", ") << "\"kernel.k_syrk_fx.ms\": " << syrk_kernel_ms_ << ", \"kernel.k_syrk_fx.launches\": " << syrk_launches_
        << ", \"kernel.k_syrk_fx.algorithmic_bytes\": " << (fx_bytes + acc_bytes)
        << ", \"kernel.k_syrk_fx.limb_macs\": "
-       << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TOOM4 ? 7.0 / 16 : SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 7 or 9 (FX/4)^2, or 3 (FX/2)^2 per product
-       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TOOM4 ? 0 : SYRK_TWO_LEVEL ? 2 : 1) << ", \"kernel.k_syrk_fx.toom4\": " << (SYRK_TOOM4 ? 1 : 0)
+       << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TOOM4K ? 21.0 / 64 : SYRK_TOOM4 ? 7.0 / 16 : SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 21 (FX/8)^2, 7 or 9 (FX/4)^2, or 3 (FX/2)^2 per product
+       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TOOM4 ? 0 : SYRK_TWO_LEVEL ? 2 : 1) << ", \"kernel.k_syrk_fx.toom4\": " << (SYRK_TOOM4 ? 1 : 0) << ", \"kernel.k_syrk_fx.toom4k\": " << (SYRK_TOOM4K ? 1 : 0)
        << ", \"host_syncs\": " << host_syncs_ << ", \"launches\": " << launch_counter().load()
        << ", \"iterations\": " << iteration_ << ", \"comm.world\": " << world_ << ", \"comm.ranks\": " << (comm_ ? comm_->ranks() : (world_ == 1 ? 1 : 0))
        << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
@@ -1640,6 +1644,23 @@ private:
       mw::store<NL>(inv, i, mw::mul(r, mw::sub(mw::from_u32<NL>(2), mw::mul(s, r))));
     });
   }
+  // the fixed-point image of a rows x cols operand: elements per group plane (kernels.hpp: fx_image_stride) and its
+  // allocation, zeroed once -- k_normalize_fx / k_fx_from_int only ever write the rows x cols elements, the pad stays zero
+  static size_t image_stride(size_t rows, size_t cols) { return std::max<size_t>(1, fx_image_stride<FX>(rows, cols, SYRK_RB)); }
+  void image_alloc(DevBuf<uint32_t> &fx, size_t stride)
+  {
+    fx.alloc(stride * fx_planes<FX>() + 4);
+    HIP_CHECK(hipMemsetAsync(fx.p, 0, fx.n * sizeof(uint32_t), stream_));
+  }
+  // k_syrk_fx3: one Toom-4 group per workgroup (7) or all seven (1)
+  static int syrk_group_split()
+  {
+    if(!SYRK_TOOM4K)
+      return 1;
+    if(const char *e = std::getenv("SDPB_HIP_SYRK_GSPLIT"))
+      return std::atoi(e) == 1 ? 1 : 7;
+    return 7;
+  }
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
   // that fills the last round of resident workgroups better; `part` grows on demand
   // ntile_sub >= 0: only the `ntile_sub` tiles tiles_dev points at, which cover the columns [col0, col1) of the lower
@@ -1649,7 +1670,7 @@ private:
   {
     if(SYRK_TOOM4 && !toomU)
       throw SolverError(4, "syrk_G: the Toom-4 image needs the column terms of syrk_column_sums");
-    const unsigned tiles = cdiv(N, 16);
+    const unsigned tiles = cdiv(N, SYRK_EDGE);
     const int ntile = ntile_sub >= 0 ? ntile_sub : (int)(tiles * (tiles + 1) / 2);
     if(col1 < 0)
       col1 = N;
@@ -1657,7 +1678,8 @@ private:
     if(ntile == 0 || idx1 <= idx0)
       return;
     const int slots = num_cus_ * syrk_waves_per_simd<FX>();
-    const int nsplit = syrk_row_splits(ntile, nrows, slots, SYRK_RB);
+    const int gsplit = syrk_group_split();
+    const int nsplit = syrk_row_splits(ntile * gsplit, nrows, slots, SYRK_RB);
     const unsigned rps = cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB;
     uint32_t *out = acc;
     if(nsplit > 1 || SYRK_TOOM4)
@@ -1668,6 +1690,10 @@ private:
       }
     if constexpr(SYRK_TOOM4)
       {
+        if constexpr(SYRK_TOOM4K)
+          launch(k_syrk_fx3<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit * gsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out,
+                 acc_stride, tiles_dev, ntile, nsplit, rps, gsplit);
+        else
         launch(k_syrk_fx2<FX, SYRK_RB, true>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out,
                acc_stride, tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
         launch(k_syrk4_finish<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, (const uint32_t *)toomU, acc,
@@ -2539,11 +2565,12 @@ public:
     const int rows = a, cols = b;
     const size_t cnt = (size_t)rows * cols;
     DevBuf<uint32_t> fx, acc, part, tl;
-    fx.alloc(cnt * fx_planes<FX>());
+    const size_t fxs = image_stride((size_t)rows, (size_t)cols);
+    image_alloc(fx, fxs);
     {
-      // pseudo-random limbs with the top bit of every word clear (valid pieces of both image layouts)
+      // pseudo-random limbs with the top bit of every word clear (valid pieces of every image layout)
       uint32_t *p = fx.p;
-      foreach(cnt * fx_planes<FX>(), [=] __device__(size_t i) {
+      foreach(fxs * fx_planes<FX>(), [=] __device__(size_t i) {
         uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -2552,17 +2579,17 @@ public:
     }
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
-    tl.upload(syrk_tile_order(cols));
+    tl.upload(syrk_tile_order(cols, 0, nullptr, SYRK_EDGE));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
     DevBuf<uint32_t> tu; // column terms of the Toom-4 image (zeros: the timing does not depend on them)
     tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
     HIP_CHECK(hipMemsetAsync(tu.p, 0, tu.n * sizeof(uint32_t), stream_));
-    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p); // warm-up (sizes `part`)
+    syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p); // warm-up (sizes `part`)
     HIP_CHECK(hipEventRecord(e0, stream_));
     for(int r = 0; r < std::max(reps, 1); ++r)
-      syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
+      syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
     HIP_CHECK(hipEventRecord(e1, stream_));
     HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -2608,17 +2635,18 @@ public:
     norms_to_inverse(nrm.ptr(), inv.ptr(), (size_t)cols);
     DevBuf<uint32_t> fx, acc, partial, tl, spart;
     DevBuf<int> qf;
-    fx.alloc(cnt * fx_planes<FX>());
-    launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT.cptr(), cnt, cols, inv.cptr(), fx.p, cnt);
+    const size_t fxs = image_stride((size_t)rows, (size_t)cols);
+    image_alloc(fx, fxs);
+    launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT.cptr(), cnt, cols, inv.cptr(), fx.p, fxs);
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
     partial.alloc((size_t)slices * (FX + 8) * cols);
     DevBuf<uint32_t> tu;
     tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
-    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
-    tl.upload(syrk_tile_order(cols));
-    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, spart, tu.p);
+    syrk_column_sums(fx.p, fxs, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
+    tl.upload(syrk_tile_order(cols, 0, nullptr, SYRK_EDGE));
+    syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, spart, tu.p);
     qf.alloc(4);
     HIP_CHECK(hipMemsetAsync(qf.p, 0, 4 * sizeof(int), stream_));
     launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows, (size_t)0,
@@ -2681,20 +2709,20 @@ public:
         }
     DevBuf<uint32_t> staged, fx, acc, partial;
     staged.upload(h);
-    fx.alloc(cnt * fx_planes<FX>());
-    launch(k_fx_from_int<FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, (const uint32_t *)staged.p, cnt, fx.p, cnt);
+    const size_t fxs = image_stride((size_t)rows, (size_t)cols);
+    image_alloc(fx, fxs);
+    launch(k_fx_from_int<FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, (const uint32_t *)staged.p, cnt, fx.p, fxs);
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
     partial.alloc((size_t)slices * (FX + 8) * cols);
     DevBuf<uint32_t> tu;
     tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
-    syrk_column_sums(fx.p, cnt, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
-    const unsigned tiles = cdiv(cols, 16);
+    syrk_column_sums(fx.p, fxs, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
     DevBuf<uint32_t> tl;
-    tl.upload(syrk_tile_order(cols));
+    tl.upload(syrk_tile_order(cols, 0, nullptr, SYRK_EDGE));
     DevBuf<uint32_t> part;
-    syrk_G(fx.p, cnt, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
+    syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
     launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows, (size_t)0,
            (size_t)cols * cols);
     HIP_CHECK(hipStreamSynchronize(stream_));

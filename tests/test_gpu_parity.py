@@ -73,7 +73,7 @@ def test_iterations_at_the_default_precision_400():
     sdp, meta, _, _ = parity.load_case("singlet_cT")
     o = Oracle(sdp, 400, meta["params"], param_prec=64)
     s = _solver(sdp, 400, parity.reference_params(meta["params"], o))
-    assert s.limbs == 16 and s.fx_frac_bits == 495
+    assert s.limbs == 16 and s.fx_frac_bits == 487
     for it in range(12):
         assert not s.iterate() and not o.iterate()
         bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=200)
@@ -94,7 +94,10 @@ def test_precision_beyond_the_compiled_widths_is_a_clear_error():
                                                         (1024, 64, 33, None), (512, 300, 50, "4"), (256, 100, 40, "16"),
                                                         (768, 130, 40, "3"), (1024, 200, 33, "2"), (1280, 64, 33, None),
                                                         (1536, 90, 20, "2"), (400, 50, 20, None),
-                                                        (664, 64, 33, "2")])
+                                                        (664, 64, 33, "2"),
+                                                        # k_syrk_fx3 (32 x 32 tiles, 2 x 2 outputs per lane): odd widths (pair loads at
+                                                        # 8-byte alignment, second column of the last pair past N), every quadrant mask
+                                                        (512, 200, 81, None), (512, 333, 113, "3"), (400, 70, 47, None), (512, 90, 96, "2")])
 def test_int_syrk_bit_exact(precision, rows, cols, splits, monkeypatch):
     from oracle.oracle import Oracle
     if splits:
