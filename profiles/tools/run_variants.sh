@@ -7,6 +7,7 @@ cp sdpb_amd/libsdpb_hip.so /tmp/libsdpb_hip.orig.so
 for v in sdpb_amd/_variants/*.so; do
   n=$(basename $v .so)
   cp $v sdpb_amd/libsdpb_hip.so
+  timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "int_syrk and 512" 2>&1 | tail -1
   timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_C4_$n.json 2>> $O/err.log
   python - "$O/bench_C4_$n.json" <<'PY'
 import json,sys

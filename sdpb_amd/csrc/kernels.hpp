@@ -1871,7 +1871,7 @@ template <int FX> constexpr bool fx_toom4k()
 #if defined(SDPB_SYRK_NO_TOOM4K)
   return false;
 #else
-  return fx_toom4<FX>() && FX == 16;
+  return fx_toom4<FX>() && (FX == 16 || FX == 32); // M3 = 2 or 4 limbs per piece: a whole number of pieces per 16-byte staging unit
 #endif
 }
 // bits per Toom-4 piece
@@ -2109,6 +2109,19 @@ template <int M2> MW_HD void piece_store(uint32_t *p, const uint32_t (&x)[M2])
 #pragma unroll
       for(int l = 0; l < M2; ++l)
         p[l] = x[l];
+    }
+}
+
+// d -= x (both A limbs, d >= x)
+template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
+{
+  uint64_t bw = 0;
+#pragma unroll
+  for(int k = 0; k < A; ++k)
+    {
+      const uint64_t t = (uint64_t)d[k] - (uint64_t)x[k] - bw;
+      d[k] = (uint32_t)t;
+      bw = (t >> 63) & 1u;
     }
 }
 
@@ -2684,7 +2697,7 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
 #ifndef SDPB_SYRK_WAVES
 #define SDPB_SYRK_WAVES (FX <= 16 ? 3 : 2) // 3 waves x 168 VGPRs hold the staging registers of the pipeline without spills
 #endif
-template <int FX> constexpr int syrk_waves_per_simd() { return SDPB_SYRK_WAVES; }
+template <int FX> constexpr int syrk_waves_per_simd();
 // nsplit in [1, 32]: fewest splits within 2% of the best occupancy of the last round.  (Up to 16 until round 4: with
 // N = 100 the output has 28 tiles, and 16 splits filled 448 of the chip's 768 workgroup slots — C3's product took
 // 2.08 ms at 8 splits, 3.8 at 4, 15 at 1: profiles/r04k_syrk_row_splits.txt; the row floor of 64 passes per split
@@ -3117,6 +3130,38 @@ __global__ void __launch_bounds__(WG)
   uint32_t w[7][Z];
   // GMP's order: w0 = f(0), w1 = f(-2), w2 = f(1), w3 = f(-1), w4 = f(2), w5 = 64 f(1/2), w6 = f(inf)
   constexpr int GRP[7] = {0, 4, 1, 2, 3, 5, 6};
+  if constexpr(fx_toom4k<FX>())
+    {
+      // k_syrk_fx3 left the sums of the 21 products, A3 limbs each: e e' = lo lo' + (mid mid' - lo lo' - hi hi') 2^H + hi hi' 2^(2H)
+      constexpr int M3 = FX / 8, A3 = 2 * M3 + 1, H = 16 * M2 - 1;
+#pragma unroll
+      for(int q = 0; q < 7; ++q)
+        {
+          uint32_t g3[3][A3];
+#pragma unroll
+          for(int u = 0; u < 3; ++u)
+            {
+              uint64_t cy = 0;
+#pragma unroll
+              for(int k = 0; k < A3; ++k)
+                {
+                  for(int s = 0; s < nsplit; ++s)
+                    cy += part[(((size_t)s * 21 + 3 * GRP[q] + u) * A3 + k) * acc_stride + idx];
+                  g3[u][k] = (uint32_t)cy;
+                  cy >>= 32;
+                }
+            }
+          sub_limbs<A3>(g3[2], g3[0]);
+          sub_limbs<A3>(g3[2], g3[1]);
+#pragma unroll
+          for(int k = 0; k < Z; ++k)
+            w[q][k] = k < A3 ? g3[0][k < A3 ? k : 0] : 0u;
+          add_shifted<Z, A3>(w[q], g3[2], H, false);
+          add_shifted<Z, A3>(w[q], g3[1], 2 * H, false);
+        }
+    }
+  else
+    {
 #pragma unroll
   for(int q = 0; q < 7; ++q)
     {
@@ -3130,6 +3175,7 @@ __global__ void __launch_bounds__(WG)
           w[q][k] = (uint32_t)cy;
           cy >>= 32;
         }
+    }
     }
   {
     uint32_t u[Z];
@@ -3163,18 +3209,6 @@ __global__ void __launch_bounds__(WG)
     acc[(size_t)k * acc_stride + idx] = g[k];
 }
 
-// d -= x (both A limbs, d >= x)
-template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
-{
-  uint64_t bw = 0;
-#pragma unroll
-  for(int k = 0; k < A; ++k)
-    {
-      const uint64_t t = (uint64_t)d[k] - (uint64_t)x[k] - bw;
-      d[k] = (uint32_t)t;
-      bw = (t >> 63) & 1u;
-    }
-}
 
 // acc(i,j) (i >= j) = G(i,j) = sum_r a'(r,i) a'(r,j) exactly as k_syrk_fx (same tiles, same
 // XCD-aware item order, same row splits), but nine M2 x M2 products per row pair.  One PASS =
@@ -3432,17 +3466,24 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 // tiling.  One SWEEP over the split's rows = one of the 21 products: a pass per block of RBG rows, the column
 // accumulators (96 bits each, 4 x 3 per lane) live in registers for the whole sweep and are folded when it ends; the
 // three sums of a Toom-4 group are recombined after its third sweep.
+#ifndef SDPB_SYRK3_PREFETCH
+#define SDPB_SYRK3_PREFETCH 1 // measured on C4 (profiles/r04s_syrk3_variants.txt): 101.9 ms against 103.8 without
+#endif
+#ifndef SDPB_SYRK3_WAVES
+#define SDPB_SYRK3_WAVES 3
+#endif
 template <int FX, int RBG>
-__global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
+__global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   k_syrk_fx3(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
              const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, int gsplit)
 {
-  // gsplit = 7: a workgroup takes ONE Toom-4 group of its (tile, row split) instead of all seven (the sweeps are
-  // independent): seven times the workgroups where the output has few tiles, and a shorter tail everywhere
-  constexpr int M2 = FX / 4, M3 = FX / 8, A3 = 2 * M3 + 1, A2 = 2 * M2 + 1, H = 16 * M2 - 1;
-  static_assert(M3 == 2, "a pair of pieces is one 16-byte load");
-  constexpr int NPAIR = RBG * 16, GL = NPAIR / WG; // 16-byte pairs per operand per pass, per lane
-  static_assert(NPAIR % WG == 0, "a pass stages a whole number of pairs per lane");
+  // gsplit = 7 (21): a workgroup takes the three products of ONE Toom-4 group (one product) of its (tile, row split)
+  // instead of all 21 (the sweeps are independent): more workgroups where the output has few tiles, a shorter tail everywhere
+  constexpr int M3 = FX / 8, A3 = 2 * M3 + 1;
+  static_assert(M3 == 2 || M3 == 4, "16-byte staging units hold whole pieces");
+  // a staged row = the M3-limb pieces of the tile's 32 columns = ROWW words = UPR 16-byte units (two pieces at M3 = 2, one at 4)
+  constexpr int ROWW = 32 * M3, UPR = ROWW / 4, NPAIR = RBG * UPR, GL = NPAIR / WG; // units per operand per pass, per lane
+  static_assert(NPAIR % WG == 0, "a pass stages a whole number of units per lane");
   const uint32_t *fx = (const uint32_t *)__builtin_assume_aligned(fx_in, 8);
   const int nitem = ntile * nsplit * gsplit, per = (nitem + 7) / 8;
   const int item = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
@@ -3450,10 +3491,10 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
     return;
   // items that follow each other share the rows and the group, i.e. the operand panels of neighbouring tiles
   const int sg = item / ntile, tile = item % ntile, split = sg / gsplit;
-  const int grp_begin = (sg % gsplit) * (7 / gsplit), grp_end = grp_begin + 7 / gsplit;
+  const int prod_begin = (sg % gsplit) * (21 / gsplit), prod_end = prod_begin + 21 / gsplit;
   const unsigned row_begin = (unsigned)split * rows_per_split;
   const unsigned row_end = (row_begin + rows_per_split < nrows && split + 1 < nsplit) ? row_begin + rows_per_split : nrows;
-  acc += (size_t)split * 7 * A2 * acc_stride;
+  acc += (size_t)split * 21 * A3 * acc_stride;
   const uint32_t tt = tile_list[tile];
   const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
@@ -3461,8 +3502,9 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   // quadrant (p, q): rows i0 + 16 p of the output against columns j0 + 16 q; workgroup-uniform
   const bool half_i = ti * 32 + 16 < N, half_j = tj * 32 + 16 < N;
   const int mask = 1 | (half_i ? 2 : 0) | ((half_j && tj < ti) ? 4 : 0) | ((half_i && half_j) ? 8 : 0); // bit p + 2 q
-  __shared__ __attribute__((aligned(16))) uint32_t sa[2 * NPAIR * 4];
-  __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NPAIR * 4];
+  // (+ 64 words: the prefetching row loop reads one row past the pass it is in)
+  __shared__ __attribute__((aligned(16))) uint32_t sa[2 * NPAIR * 4 + 64];
+  __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NPAIR * 4 + 64];
   uint64_t cc[4][2 * M3 - 1];
   uint32_t hh[4][2 * M3 - 1];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK2_NO_GLDS)
@@ -3480,9 +3522,9 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   for(int t = 0; t < GL; ++t)
     {
       const int e = threadIdx.x + t * WG;
-      const int col = e & 15, rr = e >> 4;
-      offa[t] = (uint32_t)(((size_t)rr * N + ti * 32 + 2 * col) * M3);
-      offb[t] = (uint32_t)(((size_t)rr * N + tj * 32 + 2 * col) * M3);
+      const int unit = e % UPR, rr = e / UPR;
+      offa[t] = (uint32_t)(((size_t)rr * N + ti * 32) * M3 + 4 * unit);
+      offb[t] = (uint32_t)(((size_t)rr * N + tj * 32) * M3 + 4 * unit);
     }
   auto fetch = [&](int g, unsigned r0, int into) __attribute__((always_inline)) {
     const uint32_t *base = fx + ((size_t)g * fx_stride + (size_t)r0 * (size_t)N) * M3;
@@ -3527,6 +3569,13 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   auto rows = [&](auto mask_c, int buf, uint64_t (&c)[4][2 * M3 - 1], uint32_t (&h)[4][2 * M3 - 1]) __attribute__((always_inline)) {
     constexpr int MASK = decltype(mask_c)::value;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK3_NO_ASM)
+    constexpr bool ASM_ROWS = (M3 == 2);
+#else
+    constexpr bool ASM_ROWS = false;
+#endif
+    if constexpr(ASM_ROWS)
+      {
+#if defined(__HIP_DEVICE_COMPILE__)
     // LDS reads and MACs as a few large asm statements per row (every asm statement costs a wait state), and the
     // reads invisible to the compiler's wait-count pass, which would otherwise drain the global_load_lds of the NEXT
     // pass (vmcnt(0)) before the first read of this one -- those land in the other buffer; the barrier that ends the
@@ -3574,6 +3623,58 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
       FX3_MAC_ONE(0, va.x, va.y, vb.x, vb.y);                                                                                              \
   }
     static_assert(RBG % 4 == 0 && M3 == 2, "four rows per trip, offsets in units of 8 bytes");
+#if SDPB_SYRK3_PREFETCH
+    // The reads of row r + 1 are issued before the products of row r: two register sets, each handed from the
+    // statement that issues its reads to the statement that waits for them without the compiler touching it in between.
+#define FX3_MACS(va, vb)                                                                                                                   \
+  if constexpr(MASK == 15)                                                                                                                 \
+    {                                                                                                                                      \
+      FX3_MAC_BOTH(0, 1, va.x, va.y, va.z, va.w, vb.x, vb.y);                                                                              \
+      FX3_MAC_BOTH(2, 3, va.x, va.y, va.z, va.w, vb.z, vb.w);                                                                              \
+    }                                                                                                                                      \
+  else if constexpr(MASK == 11)                                                                                                            \
+    {                                                                                                                                      \
+      FX3_MAC_BOTH(0, 1, va.x, va.y, va.z, va.w, vb.x, vb.y);                                                                              \
+      FX3_MAC_ONE(3, va.z, va.w, vb.z, vb.w);                                                                                              \
+    }                                                                                                                                      \
+  else if constexpr(MASK == 5)                                                                                                             \
+    {                                                                                                                                      \
+      FX3_MAC_ONE(0, va.x, va.y, vb.x, vb.y);                                                                                              \
+      FX3_MAC_ONE(2, va.x, va.y, vb.z, vb.w);                                                                                              \
+    }                                                                                                                                      \
+  else                                                                                                                                     \
+    FX3_MAC_ONE(0, va.x, va.y, vb.x, vb.y);
+    // wait for the set (wa, wb) that is in flight, then issue the reads of (ra, rb)
+#define FX3_NEXT(wa, wb, ra, rb, O0, O1)                                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read2_b64 %2, %4 offset0:" #O0 " offset1:" #O1 "\n\tds_read2_b64 %3, %5 offset0:" #O0            \
+               " offset1:" #O1                                                                                                             \
+               : "+v"(wa), "+v"(wb), "=&v"(ra), "=&v"(rb)                                                                                  \
+               : "v"(xa), "v"(xb)                                                                                                          \
+               : "memory")
+    u32x4 a0, b0, a1, b1;
+    {
+      const uint32_t xa = la, xb = lb;
+      asm volatile("ds_read2_b64 %0, %2 offset0:0 offset1:16\n\tds_read2_b64 %1, %3 offset0:0 offset1:16" : "=&v"(a0), "=&v"(b0) : "v"(xa), "v"(xb) : "memory");
+    }
+#pragma unroll 1
+    for(int rr = 0; rr < RBG; rr += 4)
+      {
+        const uint32_t xa = la + rr * 256, xb = lb + rr * 256; // a staged row is 64 words
+        FX3_NEXT(a0, b0, a1, b1, 32, 48);
+        FX3_MACS(a0, b0)
+        FX3_NEXT(a1, b1, a0, b0, 64, 80);
+        FX3_MACS(a1, b1)
+        FX3_NEXT(a0, b0, a1, b1, 96, 112);
+        FX3_MACS(a0, b0)
+        // row rr + 4; past the last row of the pass this reads the first row of the other buffer (or, behind sb, LDS
+        // that is not ours): the data is dropped
+        FX3_NEXT(a1, b1, a0, b0, 128, 144);
+        FX3_MACS(a1, b1)
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(b0)::"memory");
+#undef FX3_NEXT
+#undef FX3_MACS
+#else
 #pragma unroll 1
     for(int rr = 0; rr < RBG; rr += 4)
       {
@@ -3583,101 +3684,96 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
         FX3_ROW(64, 80)
         FX3_ROW(96, 112)
       }
+#endif
 #undef FX3_ROW
 #undef FX3_MAC_ONE
 #undef FX3_MAC_BOTH
 #undef FX3_P
-#else
-    // column x of the tile sits at word 2 x of a staged row: the lane's two pieces are 16 columns = 32 words apart
-    const uint32_t *pa = sa + buf * NPAIR * 4 + li * M3, *pb = sb + buf * NPAIR * 4 + lj * M3;
-#pragma unroll SDPB_SYRK2_UNROLL
-    for(int rr = 0; rr < RBG; ++rr)
-      {
-        uint32_t a0[M3], a1[M3], b0[M3], b1[M3];
-        piece_load<M3>(pa + rr * 64, a0);
-        piece_load<M3>(pb + rr * 64, b0);
-        if constexpr((MASK & 10) != 0)
-          piece_load<M3>(pa + rr * 64 + 32, a1);
-        if constexpr((MASK & 12) != 0)
-          piece_load<M3>(pb + rr * 64 + 32, b1);
-        SyrkColumns<M3, 0>::run(a0, b0, c[0], h[0]);
-        if constexpr((MASK & 2) != 0)
-          SyrkColumns<M3, 0>::run(a1, b0, c[1], h[1]);
-        if constexpr((MASK & 4) != 0)
-          SyrkColumns<M3, 0>::run(a0, b1, c[2], h[2]);
-        if constexpr((MASK & 8) != 0)
-          SyrkColumns<M3, 0>::run(a1, b1, c[3], h[3]);
-      }
 #endif
+      }
+    else
+      {
+        // column x of the tile sits at word M3 x of a staged row: the lane's two pieces are 16 columns apart
+        const uint32_t *pa = sa + buf * NPAIR * 4 + li * M3, *pb = sb + buf * NPAIR * 4 + lj * M3;
+#pragma unroll SDPB_SYRK2_UNROLL
+        for(int rr = 0; rr < RBG; ++rr)
+          {
+            uint32_t a0[M3], a1[M3], b0[M3], b1[M3];
+            piece_load<M3>(pa + rr * ROWW, a0);
+            piece_load<M3>(pb + rr * ROWW, b0);
+            if constexpr((MASK & 10) != 0)
+              piece_load<M3>(pa + rr * ROWW + 16 * M3, a1);
+            if constexpr((MASK & 12) != 0)
+              piece_load<M3>(pb + rr * ROWW + 16 * M3, b1);
+            SyrkColumns<M3, 0>::run(a0, b0, c[0], h[0]);
+            if constexpr((MASK & 2) != 0)
+              SyrkColumns<M3, 0>::run(a1, b0, c[1], h[1]);
+            if constexpr((MASK & 4) != 0)
+              SyrkColumns<M3, 0>::run(a0, b1, c[2], h[2]);
+            if constexpr((MASK & 8) != 0)
+              SyrkColumns<M3, 0>::run(a1, b1, c[3], h[3]);
+          }
+      }
   };
-  // One sweep over the split's rows per product (group, u): 36 accumulator registers live in the row loop instead of
-  // the 108 of three products at once; the three folded sums of a group (A3 limbs per output) wait for its last sweep.
-  for(int grp = grp_begin; grp < grp_end; ++grp)
+  // One sweep over the split's rows per product: its accumulators are the only sums a lane holds (36 registers at M3 = 2,
+  // 84 at M3 = 4); the folded sum (A3 limbs per output) goes to plane (split, product) of the output, and
+  // k_syrk4_finish recombines the three products of a Toom-4 group.
+  for(int prod = prod_begin; prod < prod_end; ++prod)
     {
-      uint32_t g3[3][4][A3];
 #pragma unroll
-      for(int u = 0; u < 3; ++u)
+      for(int o = 0; o < 4; ++o)
+#pragma unroll
+        for(int k = 0; k < 2 * M3 - 1; ++k)
+          {
+            cc[o][k] = 0;
+            hh[o][k] = 0;
+          }
+      if(prod > prod_begin)
+        __syncthreads(); // every wavefront has left the last pass of the previous sweep
+      fetch(prod, row_begin, 0);
+      store(0);
+      __syncthreads();
+      // the row blocks of the sweep; the quadrant mask is chosen outside the loop, so that the accumulators stay in
+      // the same registers from block to block
+      auto sweep = [&](auto mask_c) __attribute__((always_inline)) {
+        int buf = 0;
+        for(unsigned r0 = row_begin; r0 < row_end; r0 += RBG)
+          {
+            // (after the last block of the sweep: a block that exists, staged and never read)
+            fetch(prod, r0 + RBG < row_end ? r0 + RBG : row_begin, buf ^ 1);
+            rows(mask_c, buf, cc, hh);
+            store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+          }
+      };
+      switch(mask)
         {
-#pragma unroll
-          for(int o = 0; o < 4; ++o)
-#pragma unroll
-            for(int k = 0; k < 2 * M3 - 1; ++k)
-              {
-                cc[o][k] = 0;
-                hh[o][k] = 0;
-              }
-          if(grp > grp_begin || u > 0)
-            __syncthreads(); // every wavefront has left the last pass of the previous sweep
-          fetch(3 * grp + u, row_begin, 0);
-          store(0);
-          __syncthreads();
-          int buf = 0;
-          for(unsigned r0 = row_begin; r0 < row_end; r0 += RBG)
-            {
-              // (after the last block of the sweep: a block that exists, staged and never read)
-              fetch(3 * grp + u, r0 + RBG < row_end ? r0 + RBG : row_begin, buf ^ 1);
-              switch(mask)
-                {
-                case 15: rows(std::integral_constant<int, 15>(), buf, cc, hh); break;
-                case 11: rows(std::integral_constant<int, 11>(), buf, cc, hh); break; // diagonal tile: quadrant (0, 1) lies above the diagonal
-                case 5: rows(std::integral_constant<int, 5>(), buf, cc, hh); break;   // last tile row, fewer than 17 of its 32 rows inside N
-                default: rows(std::integral_constant<int, 1>(), buf, cc, hh); break;  // ... and its diagonal tile
-                }
-              store(buf ^ 1);
-              __syncthreads();
-              buf ^= 1;
-            }
-#pragma unroll
-          for(int o = 0; o < 4; ++o)
-            {
-#pragma unroll
-              for(int k = 0; k < A3; ++k)
-                g3[u][o][k] = 0;
-              syrk_fold<M3, A3>(g3[u][o], cc[o], hh[o]);
-            }
+        case 15: sweep(std::integral_constant<int, 15>()); break;
+        case 11: sweep(std::integral_constant<int, 11>()); break; // diagonal tile: quadrant (0, 1) lies above the diagonal
+        case 5: sweep(std::integral_constant<int, 5>()); break;   // last tile row, fewer than 17 of its 32 rows inside N
+        default: sweep(std::integral_constant<int, 1>()); break;  // ... and its diagonal tile
         }
-      // e e' = lo lo' + (mid mid' - lo lo' - hi hi') 2^H + hi hi' 2^(2H)
 #pragma unroll
       for(int o = 0; o < 4; ++o)
         {
           const int i = i0 + 16 * (o & 1), j = j0 + 16 * (o >> 1);
           if(!((mask >> o) & 1) || i >= N || j > i)
             continue;
-          sub_limbs<A3>(g3[2][o], g3[0][o]);
-          sub_limbs<A3>(g3[2][o], g3[1][o]);
-          uint32_t w[A2];
+          uint32_t g[A3];
 #pragma unroll
-          for(int k = 0; k < A2; ++k)
-            w[k] = k < A3 ? g3[0][o][k < A3 ? k : 0] : 0u;
-          add_shifted<A2, A3>(w, g3[2][o], H, false);
-          add_shifted<A2, A3>(w, g3[1][o], 2 * H, false);
+          for(int k = 0; k < A3; ++k)
+            g[k] = 0;
+          syrk_fold<M3, A3>(g, cc[o], hh[o]);
           const size_t at = (size_t)i + (size_t)j * N;
 #pragma unroll
-          for(int k = 0; k < A2; ++k)
-            acc[(size_t)(grp * A2 + k) * acc_stride + at] = w[k];
+          for(int k = 0; k < A3; ++k)
+            acc[(size_t)(prod * A3 + k) * acc_stride + at] = g[k];
         }
     }
 }
+
+template <int FX> constexpr int syrk_waves_per_simd() { return fx_toom4k<FX>() ? SDPB_SYRK3_WAVES : SDPB_SYRK_WAVES; }
 
 // Remove the bias in place (after any cross-GPU sum): for i >= j
 //   acc(i,j) <- G(i,j) - C (S_i + S_j) + n C^2 = sum_r v_ri v_rj   (two's complement),

@@ -249,7 +249,7 @@ template <int NL> class Solver : public SolverBase
   static constexpr bool SYRK_TOOM4K = fx_toom4k<FX>();       // ... and one Karatsuba level below them: 21 (FX/8)^2 products (k_syrk_fx3)
   static constexpr int SYRK_EDGE = syrk_tile_edge<FX>();     // output tile of the syrk kernel in use
   static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>() || SYRK_TOOM4; // piece-major image: nine (two Karatsuba levels) or seven pieces
-  static constexpr int SYRK_PART_PLANES = SYRK_TOOM4 ? 7 * (2 * (FX / 4) + 1) : ACCW; // planes one row split writes
+  static constexpr int SYRK_PART_PLANES = SYRK_TOOM4K ? 21 * (2 * (FX / 8) + 1) : SYRK_TOOM4 ? 7 * (2 * (FX / 4) + 1) : ACCW; // planes one row split writes
   // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
 #ifndef SDPB_SYRK2_RBG
 #define SDPB_SYRK2_RBG (FX >= 32 ? 16 : 32)
@@ -1652,13 +1652,16 @@ private:
     fx.alloc(stride * fx_planes<FX>() + 4);
     HIP_CHECK(hipMemsetAsync(fx.p, 0, fx.n * sizeof(uint32_t), stream_));
   }
-  // k_syrk_fx3: one Toom-4 group per workgroup (7) or all seven (1)
+  // k_syrk_fx3: the 21 products of a (tile, row split) in one workgroup (1), one Toom-4 group each (7), or one product each (21)
   static int syrk_group_split()
   {
     if(!SYRK_TOOM4K)
       return 1;
     if(const char *e = std::getenv("SDPB_HIP_SYRK_GSPLIT"))
-      return std::atoi(e) == 1 ? 1 : 7;
+      {
+        const int g = std::atoi(e);
+        return g == 1 || g == 21 ? g : 7;
+      }
     return 7;
   }
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when

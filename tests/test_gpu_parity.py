@@ -97,7 +97,8 @@ def test_precision_beyond_the_compiled_widths_is_a_clear_error():
                                                         (664, 64, 33, "2"),
                                                         # k_syrk_fx3 (32 x 32 tiles, 2 x 2 outputs per lane): odd widths (pair loads at
                                                         # 8-byte alignment, second column of the last pair past N), every quadrant mask
-                                                        (512, 200, 81, None), (512, 333, 113, "3"), (400, 70, 47, None), (512, 90, 96, "2")])
+                                                        (512, 200, 81, None), (512, 333, 113, "3"), (400, 70, 47, None), (512, 90, 96, "2"),
+                                                        (1024, 100, 81, None), (1024, 150, 47, "3")])
 def test_int_syrk_bit_exact(precision, rows, cols, splits, monkeypatch):
     from oracle.oracle import Oracle
     if splits:
