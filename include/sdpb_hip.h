@@ -143,9 +143,10 @@ int sdpb_hip_limbs(sdpb_hip_ctx *ctx);
 /* Fraction bits FB of the fixed-point image of the normalised P' that the exact integer
  * Q' = P'^T P' is formed from (the reference keeps El::gmp::Precision() bits,
  * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here, with FX = limbs - 2 rounded up to a multiple of
- * four, FB = 32 FX - 25 at --precision 400 ... 512 (FX = 16, Toom-4 x Karatsuba image: 487 bits),
- * 32 FX - 17 above (Toom-4 image: 751 bits at 768, 1007 at 1024) and 32 (limbs-2) - 7 at 128 and 256 bits
- * (two Karatsuba levels)): inputs of sdpb_hip_op_int_syrk obey |v| < 2^FB. */
+ * four, FB = 32 FX - 25 at --precision 400 ... 1024 (FX = 16, 24, 32, Toom-4 x Karatsuba image: 487 bits
+ * at 400 ... 512, 743 at 640 ... 768, 999 at 1024), 32 FX - 17 above (Toom-4 image: 1263 bits at 1280,
+ * 1519 at 1536) and 32 (limbs-2) - 7 at 128 and 256 bits (two Karatsuba levels)): inputs of
+ * sdpb_hip_op_int_syrk obey |v| < 2^FB. */
 int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx);
 /* Measurement aid (bench/profiling only, never on the solve path): average HIP-event time in
  * ms of `reps` launches of one kernel of the iteration on synthetic device-resident operands.

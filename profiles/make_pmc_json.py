@@ -27,15 +27,16 @@ def main():
     main_k = [k for k in fetch if k.startswith("k_syrk_fx")][0]
     side = [k for k in fetch if k.startswith(("k_syrk4_finish", "k_syrk_reduce"))]
     copy = [k for k in fetch if k.startswith("k_copy16")]
-    f_kb = fetch[main_k][1] + sum(fetch[k][1] for k in side)
+    f_kb = fetch[main_k][1]                            # 16 B/lane global_load_lds: counted half
+    f_side_kb = sum(fetch[k][1] for k in side)        # 4 B/lane loads of the finishing kernel: counted in full
     w_kb = write[main_k][1] + sum(write.get(k, (0, 0.0))[1] for k in side)
     rec = {
         "kernel": main_k + "".join(" + " + k for k in side),
         "workload": "C4 J=600 N=1000 P_tot=40000 p=512, 1 GPU (bench.py --steps 2 --warmup 1 under rocprofv3 --pmc, one counter per pass)",
         "kernel_source_digest": bench.syrk_source_digest(),
-        "FETCH_SIZE_KB_per_launch_raw": f_kb, "WRITE_SIZE_KB_per_launch_raw": w_kb,
+        "FETCH_SIZE_KB_per_launch_raw": f_kb, "FETCH_SIZE_KB_per_launch_finishing_kernels": f_side_kb, "WRITE_SIZE_KB_per_launch_raw": w_kb,
         "fetch_correction": 2.0,
-        "hbm_bytes_per_launch": 2.0 * f_kb * 1024 + w_kb * 1024,
+        "hbm_bytes_per_launch": 2.0 * f_kb * 1024 + f_side_kb * 1024 + w_kb * 1024,
         "calibration": ("same runs: k_copy16 (16 B/lane, 1 GiB in, 1 GiB out) reads FETCH_SIZE %.1f KB and writes WRITE_SIZE %.1f KB "
                         "(MI355X_MICROARCH.md: 16 B/lane streams count half in FETCH_SIZE on gfx950; the syrk fetches its pieces with "
                         "16 B/lane global_load_lds_dwordx4)" % (fetch[copy[0]][1], write[copy[0]][1])) if copy else None,

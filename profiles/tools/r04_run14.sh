@@ -18,3 +18,12 @@ except Exception as e: print(sys.argv[1], "unreadable", e)
 PY
 done
 tail -5 $O/err.log
+# one product per workgroup where the output has few tiles?
+SDPB_HIP_SYRK_GSPLIT=21 timeout 600 python bench.py --workload C3 --steps 20 --warmup 5 --no-cpu-baseline 2>> $O/err.log | python -c "
+import json,sys
+d=[json.loads(l) for l in sys.stdin if l.startswith('{\"metric\"')][-1]
+print('C3 gsplit=21', d['value'], d['ms_per_step'], 'syrk', d['roofline']['launch_ms'])"
+SDPB_HIP_SYRK_GSPLIT=21 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>> $O/err.log | python -c "
+import json,sys
+d=[json.loads(l) for l in sys.stdin if l.startswith('{\"metric\"')][-1]
+print('C4 gsplit=21', d['value'], d['ms_per_step'], 'syrk', d['roofline']['launch_ms'])"

@@ -1858,20 +1858,20 @@ template <int FX> constexpr bool fx_toom4()
   return FX % 4 == 0 && FX >= 16 && FX <= SDPB_TOOM4_MAX_FX; // 512 bits and up: below, 17 bits are too large a share of the image
 #endif
 }
-// TOOM-4 x KARATSUBA (fx_toom4k<FX>(): FX = 16, i.e. --precision 400 ... 512): each of the seven evaluated pieces
+// TOOM-4 x KARATSUBA (fx_toom4k<FX>(): FX = 16, 24, 32, i.e. --precision 400 ... 1024): each of the seven evaluated pieces
 // e < 2^(32 M2 - 2) is split once more, e = e_lo + e_hi 2^H with halves of H = 16 M2 - 1 bits and e_mid = e_lo + e_hi
 // < 2^(16 M2), so a row pair costs 21 products of M3 x M3 limbs (M3 = FX/8): 84 limb products at FX = 16 instead of the
 // 112 of Toom-4 alone.  The two spare bits per evaluated piece come out of the piece width: w = 32 M2 - 6, hence
-// FB = 4 w - 1 = 32 FX - 25 (487 fraction bits at --precision 512).  Image: 21 M3-limb pieces per element, piece-major,
-// group 3 g + u with g the Toom-4 group above and u in (lo, hi, mid); k_syrk_fx3 recombines the three sums of a
-// Toom-4 group in registers (e e' = lo lo' + (mid mid' - lo lo' - hi hi') 2^H + hi hi' 2^(2H)) and writes what
-// k_syrk_fx2<.., true> writes, so k_syrk4_finish and everything after it are shared.
+// FB = 4 w - 1 = 32 FX - 25 (487 fraction bits at --precision 512, 743 at 768, 999 at 1024).  Image: 21 M3-limb pieces per element, piece-major,
+// group 3 g + u with g the Toom-4 group above and u in (lo, hi, mid); k_syrk_fx3 sums the 21 products over the rows and
+// k_syrk4_finish recombines the three of a Toom-4 group (e e' = lo lo' + (mid mid' - lo lo' - hi hi') 2^H + hi hi' 2^(2H))
+// before it interpolates, so everything after the product sums is shared with k_syrk_fx2<.., true>.
 template <int FX> constexpr bool fx_toom4k()
 {
 #if defined(SDPB_SYRK_NO_TOOM4K)
   return false;
 #else
-  return fx_toom4<FX>() && (FX == 16 || FX == 32); // M3 = 2 or 4 limbs per piece: a whole number of pieces per 16-byte staging unit
+  return fx_toom4<FX>() && (FX == 16 || FX == 24 || FX == 32); // M3 = 2, 3, 4 limbs per piece (above, the 4 x (2 M3 - 1) x 3 accumulator registers of a lane no longer fit)
 #endif
 }
 // bits per Toom-4 piece
@@ -2569,32 +2569,42 @@ __global__ void __launch_bounds__(WG) k_fx_colsum_final(const uint32_t *partial,
     acc[(size_t)k * acc_stride + (size_t)N * N + col] = w[k];
 }
 
-// Lower-triangle 16x16 tiles of an N x N output, enumerated super-block by super-block
+// Lower-triangle tiles of an N x N output, enumerated super-block by super-block
 // (8x8 tiles) so that consecutive entries share operand panels.
-// split_tile > 0: the tiles of the columns left of tile column `split_tile` come first (super-block order inside
-// each group), *count_left = how many they are -- the two launches of the chunked Q' take the two halves of the list
+// split_col > 0: the tiles that hold outputs of the columns [0, split_col) come first (super-block order inside each
+// group), *count_left = how many they are; the tiles that hold outputs of the columns [split_col, N) follow -- the two
+// launches of the chunked Q' take the two parts of the list.  Where split_col is not a multiple of the tile edge, the
+// tiles of the straddling tile column are in BOTH parts (their products are computed twice; each part's finishing
+// kernel reads only its own columns).
 // edge: 16, or 32 for k_syrk_fx3 (super-blocks of 4x4 tiles then cover the same 128 columns)
-inline std::vector<uint32_t> syrk_tile_order(int N, int split_tile = 0, int *count_left = nullptr, int edge = 16)
+inline std::vector<uint32_t> syrk_tile_order(int N, int split_col = 0, int *count_left = nullptr, int edge = 16)
 {
   int SB = edge == 16 ? 8 : 4;
   if(const char *env = std::getenv("SDPB_HIP_SYRK_SB")) // tuning knob: super-block edge in tiles
     SB = std::max(1, std::atoi(env));
   const int tiles = (N + edge - 1) / edge, nsb = (tiles + SB - 1) / SB;
-  std::vector<uint32_t> out;
+  std::vector<uint32_t> all;
   for(int bi = 0; bi < nsb; ++bi)
     for(int bj = 0; bj <= bi; ++bj)
       for(int ti = bi * SB; ti < std::min(tiles, (bi + 1) * SB); ++ti)
         for(int tj = bj * SB; tj < std::min(tiles, (bj + 1) * SB); ++tj)
           if(tj <= ti)
-            out.push_back((uint32_t)ti << 16 | (uint32_t)tj);
-  if(split_tile > 0)
+            all.push_back((uint32_t)ti << 16 | (uint32_t)tj);
+  if(split_col <= 0)
     {
-      std::stable_partition(out.begin(), out.end(), [=](uint32_t t) { return (int)(t & 0xffffu) < split_tile; });
       if(count_left)
-        *count_left = (int)std::count_if(out.begin(), out.end(), [=](uint32_t t) { return (int)(t & 0xffffu) < split_tile; });
+        *count_left = (int)all.size();
+      return all;
     }
-  else if(count_left)
+  std::vector<uint32_t> out;
+  for(uint32_t t : all)
+    if((int)(t & 0xffffu) * edge < split_col)
+      out.push_back(t);
+  if(count_left)
     *count_left = (int)out.size();
+  for(uint32_t t : all)
+    if(((int)(t & 0xffffu) + 1) * edge > split_col)
+      out.push_back(t);
   return out;
 }
 
@@ -2702,16 +2712,23 @@ template <int FX> constexpr int syrk_waves_per_simd();
 // N = 100 the output has 28 tiles, and 16 splits filled 448 of the chip's 768 workgroup slots — C3's product took
 // 2.08 ms at 8 splits, 3.8 at 4, 15 at 1: profiles/r04k_syrk_row_splits.txt; the row floor of 64 passes per split
 // still applies.)
+// max_rows > 0 (k_syrk_fx3): at least so many splits that one has no more rows than that.  The workgroups of an XCD that
+// stream the same operand panels drift apart by no more than a split's rows, so short splits are what lets them meet in
+// that XCD's L2: on C4 (profiles/r04x_syrk3_fetch_vs_splits.txt) FETCH_SIZE per launch 99.7 M KB with 2 splits of 20 000
+// rows, 78 with 8, 49 with 16 (2500 rows: same kernel time), 22 with 32 (+ 3.5 % time: the finishing kernel adds 32 x 105 planes).
 constexpr int SYRK_MAX_SPLITS = 32;
-inline int syrk_row_splits(int ntile, unsigned nrows, int slots, int rb)
+inline int syrk_row_splits(int ntile, unsigned nrows, int slots, int rb, unsigned max_rows = 0)
 {
   if(const char *env = std::getenv("SDPB_HIP_SYRK_SPLITS")) // tests force the split path on small inputs
     return std::max(1, std::min(SYRK_MAX_SPLITS, std::atoi(env)));
-  int best = 1;
+  int smin = 1;
+  while(max_rows && smin < SYRK_MAX_SPLITS && nrows / (unsigned)smin > max_rows && nrows / (unsigned)(smin + 1) >= 64u * (unsigned)rb)
+    ++smin;
+  int best = smin;
   double best_eff = 0;
-  for(int s = 1; s <= SYRK_MAX_SPLITS; ++s)
+  for(int s = smin; s <= SYRK_MAX_SPLITS; ++s)
     {
-      if(s > 1 && nrows / (unsigned)s < 64u * (unsigned)rb)
+      if(s > smin && nrows / (unsigned)s < 64u * (unsigned)rb)
         break;
       const double items = (double)ntile * s, rounds = std::ceil(items / slots), eff = items / (rounds * slots);
       if(eff > best_eff + 0.02)
@@ -3455,17 +3472,17 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   }
 }
 
-// The Toom-4 x Karatsuba product (fx_toom4k<FX>()): acc as k_syrk_fx2<FX, RBG, true> leaves it -- the seven sums
-// sum_r e_g(r,i) e_g(r,j), A2 limbs each, per row split -- from the 21-group image of M3-limb pieces.
+// The Toom-4 x Karatsuba product (fx_toom4k<FX>()): the sums over a row split of the 21 products x(r,i) x(r,j) of the
+// M3-limb pieces of the 21-group image, A3 = 2 M3 + 1 limbs each, plane (split * 21 + product) * A3 + limb of the output;
+// k_syrk4_finish adds the splits, recombines the three products of a Toom-4 group and interpolates.
 // A workgroup owns a 32 x 32 tile, a lane 2 x 2 outputs: i in {i0, i0 + 16}, j in {j0, j0 + 16} with i0 = 32 ti + li,
 // j0 = 32 tj + lj, so per staged row it reads two pieces of each operand (8 B each at M3 = 2: the i pieces
-// conflict-free, the j pieces a broadcast) for four M3 x M3 products -- the same 16 MAC pairs per 32 B of LDS reads
-// as the 4 x 4-limb product of k_syrk_fx2, and the same staging: 16-byte global_load_lds of a PAIR of adjacent
-// columns' pieces, [row][column][M3 limbs] in LDS.  Quadrants of the tile that hold no output (above the diagonal of
-// a diagonal tile, past column N) are skipped workgroup-wide, so the executed products are those of the 16 x 16
-// tiling.  One SWEEP over the split's rows = one of the 21 products: a pass per block of RBG rows, the column
-// accumulators (96 bits each, 4 x 3 per lane) live in registers for the whole sweep and are folded when it ends; the
-// three sums of a Toom-4 group are recombined after its third sweep.
+// conflict-free, the j pieces a broadcast) for four M3 x M3 products -- at M3 = 2 the same 16 MAC pairs per 32 B of LDS
+// reads as the 4 x 4-limb product of k_syrk_fx2, and the same staging: 16-byte global_load_lds units of a row of
+// adjacent columns' pieces, [row][column][M3 limbs] in LDS.  Quadrants of the tile that hold no output (above the
+// diagonal of a diagonal tile, past column N) are skipped workgroup-wide, so the executed products are those of the
+// 16 x 16 tiling.  One SWEEP over the split's rows = one of the 21 products: a pass per block of RBG rows, the column
+// accumulators (96 bits each, 4 x (2 M3 - 1) per lane) live in registers for the whole sweep and are folded when it ends.
 #ifndef SDPB_SYRK3_PREFETCH
 #define SDPB_SYRK3_PREFETCH 1 // measured on C4 (profiles/r04s_syrk3_variants.txt): 101.9 ms against 103.8 without
 #endif
@@ -3480,11 +3497,12 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   // gsplit = 7 (21): a workgroup takes the three products of ONE Toom-4 group (one product) of its (tile, row split)
   // instead of all 21 (the sweeps are independent): more workgroups where the output has few tiles, a shorter tail everywhere
   constexpr int M3 = FX / 8, A3 = 2 * M3 + 1;
-  static_assert(M3 == 2 || M3 == 4, "16-byte staging units hold whole pieces");
-  // a staged row = the M3-limb pieces of the tile's 32 columns = ROWW words = UPR 16-byte units (two pieces at M3 = 2, one at 4)
+  static_assert(M3 >= 2 && M3 <= 4, "accumulators of 2 x 2 outputs in registers");
+  // a staged row = the M3-limb pieces of the tile's 32 columns = ROWW words = UPR 16-byte units (a unit is two pieces at
+  // M3 = 2, one at 4, and straddles pieces at 3: the row is contiguous in the image and in LDS either way)
   constexpr int ROWW = 32 * M3, UPR = ROWW / 4, NPAIR = RBG * UPR, GL = NPAIR / WG; // units per operand per pass, per lane
   static_assert(NPAIR % WG == 0, "a pass stages a whole number of units per lane");
-  const uint32_t *fx = (const uint32_t *)__builtin_assume_aligned(fx_in, 8);
+  const uint32_t *fx = (const uint32_t *)__builtin_assume_aligned(fx_in, 4);
   const int nitem = ntile * nsplit * gsplit, per = (nitem + 7) / 8;
   const int item = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
   if((int)(blockIdx.x / 8) >= per || item >= nitem)

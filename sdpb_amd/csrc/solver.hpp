@@ -248,6 +248,7 @@ template <int NL> class Solver : public SolverBase
   static constexpr bool SYRK_TOOM4 = fx_toom4<FX>();         // seven (FX/4)^2 products per row pair (k_syrk_fx2<.., true> + k_syrk4_finish)
   static constexpr bool SYRK_TOOM4K = fx_toom4k<FX>();       // ... and one Karatsuba level below them: 21 (FX/8)^2 products (k_syrk_fx3)
   static constexpr int SYRK_EDGE = syrk_tile_edge<FX>();     // output tile of the syrk kernel in use
+  static constexpr unsigned SYRK_SPLIT_ROWS = SYRK_TOOM4K ? 2560u : 0u; // rows per row split of k_syrk_fx3 at most (kernels.hpp: syrk_row_splits)
   static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>() || SYRK_TOOM4; // piece-major image: nine (two Karatsuba levels) or seven pieces
   static constexpr int SYRK_PART_PLANES = SYRK_TOOM4K ? 21 * (2 * (FX / 8) + 1) : SYRK_TOOM4 ? 7 * (2 * (FX / 4) + 1) : ACCW; // planes one row split writes
   // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
@@ -708,7 +709,7 @@ private:
     {
       // partial outputs of the row-split syrk (sized once, here, not inside the iteration)
       const unsigned tiles = cdiv(N_, SYRK_EDGE);
-      const int nsplit = syrk_row_splits((int)(tiles * (tiles + 1) / 2) * syrk_group_split(), (unsigned)Ptot_, num_cus_ * syrk_waves_per_simd<FX>(), SYRK_RB);
+      const int nsplit = syrk_row_splits((int)(tiles * (tiles + 1) / 2) * syrk_group_split(), (unsigned)Ptot_, num_cus_ * syrk_waves_per_simd<FX>(), SYRK_RB, SYRK_SPLIT_ROWS);
       if(nsplit > 1 || SYRK_TOOM4)
         syrk_part_.alloc((size_t)nsplit * SYRK_PART_PLANES * acc_stride_);
       if(SYRK_TOOM4)
@@ -760,16 +761,19 @@ private:
       const unsigned tiles = cdiv(N_, SYRK_EDGE);
       chase_ntile_ = (int)(tiles * (tiles + 1) / 2);
       chase_hA_ = std::max(step, (panels / 2) / step * step);
-      if((PB * chase_hA_) % SYRK_EDGE != 0) // the chunk boundary is a tile boundary
-        chase_hA_ += step;
       chase_cA_ = PB * chase_hA_;
       q_chase_ = want && !dist_cholq_ && !(overlap_syrk_ && world_ == 1) && chase_hA_ < panels && chase_cA_ < N_; // the same decision on every rank
       if(q_chase_)
         {
-          syrk_tiles_.upload(syrk_tile_order(N_, chase_cA_ / SYRK_EDGE, &chase_ntileA_, SYRK_EDGE));
+          {
+            // (where the chunk boundary is not a tile boundary the straddling tile column is in both parts of the list)
+            const std::vector<uint32_t> order = syrk_tile_order(N_, chase_cA_, &chase_ntileA_, SYRK_EDGE);
+            chase_ntile_ = (int)order.size();
+            syrk_tiles_.upload(order);
+          }
           const int slots = num_cus_ * syrk_waves_per_simd<FX>();
-          const int ns = std::max(syrk_row_splits(chase_ntileA_ * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB),
-                                  syrk_row_splits((chase_ntile_ - chase_ntileA_) * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB));
+          const int ns = std::max(syrk_row_splits(chase_ntileA_ * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB, SYRK_SPLIT_ROWS),
+                                  syrk_row_splits((chase_ntile_ - chase_ntileA_) * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB, SYRK_SPLIT_ROWS));
           if((ns > 1 || SYRK_TOOM4) && syrk_part_.n < (size_t)ns * SYRK_PART_PLANES * acc_stride_)
             syrk_part_.alloc((size_t)ns * SYRK_PART_PLANES * acc_stride_);
         }
@@ -1660,9 +1664,9 @@ private:
     if(const char *e = std::getenv("SDPB_HIP_SYRK_GSPLIT"))
       {
         const int g = std::atoi(e);
-        return g == 1 || g == 21 ? g : 7;
+        return g == 1 || g == 7 ? g : 21;
       }
-    return 7;
+    return 21; // measured (profiles/r04s_syrk3_variants.txt): C4 101.6 ms against 102.8 with 7, C3 1.23 against 1.55 ms
   }
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
   // that fills the last round of resident workgroups better; `part` grows on demand
@@ -1682,7 +1686,7 @@ private:
       return;
     const int slots = num_cus_ * syrk_waves_per_simd<FX>();
     const int gsplit = syrk_group_split();
-    const int nsplit = syrk_row_splits(ntile * gsplit, nrows, slots, SYRK_RB);
+    const int nsplit = syrk_row_splits(ntile * gsplit, nrows, slots, SYRK_RB, SYRK_SPLIT_ROWS);
     const unsigned rps = cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB;
     uint32_t *out = acc;
     if(nsplit > 1 || SYRK_TOOM4)

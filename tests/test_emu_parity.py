@@ -28,7 +28,7 @@ def test_emulated_library_matches_reference_golden(name, limit):
 
 @pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (128, 70, 21, "3"), (512, 45, 18, None),
                                                         (512, 100, 18, "3"), (512, 40, 47, None), (512, 70, 81, "2"), (512, 33, 34, None),
-                                                        (768, 33, 17, None), (664, 20, 17, None),
+                                                        (768, 33, 17, None), (768, 37, 45, "2"), (664, 20, 17, None),
                                                         (1024, 40, 18, None), (1024, 40, 18, "2"), (1024, 35, 49, None), (1280, 36, 17, None),
                                                         (1280, 70, 17, "2")])
 def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
@@ -39,11 +39,11 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     sdp, meta, _, _ = parity.load_case("1d")
     s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
     o = Oracle(sdp, precision)
-    fb = s.fx_frac_bits           # 32 FX - 25 (Toom-4 x Karatsuba: FX = 16, 32), - 17 (Toom-4: FX = 24, 40, 48), - 7 (two Karatsuba levels: other FX % 4 == 0), else - 3
+    fb = s.fx_frac_bits           # 32 FX - 25 (Toom-4 x Karatsuba: FX = 16, 24, 32), - 17 (Toom-4: FX = 40, 48), - 7 (two Karatsuba levels: other FX % 4 == 0), else - 3
     fx = s.limbs - 2
     if fx >= 14 and fx % 4:
         fx += 4 - fx % 4      # kernels.hpp: fx_limbs — from 400 bits up the image is padded to a multiple of four limbs
-    assert fb == 32 * fx - (25 if fx in (16, 32) else 17 if fx in (24, 40, 48) else 7 if fx % 4 == 0 else 3)
+    assert fb == 32 * fx - (25 if fx in (16, 24, 32) else 17 if fx in (40, 48) else 7 if fx % 4 == 0 else 3)
     rng = random.Random(7)
     vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
     vals[5] = 0
@@ -54,8 +54,8 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
     # exactly at / next to the split points of the image a' = v + 2^fb (Karatsuba: first and second level;
     # Toom-4: the piece boundaries at multiples of 8 fx - 4 bits)
     # (Toom-4 x Karatsuba: pieces of 8 fx - 6 bits, halves of 4 fx - 1 bits)
-    for k, bit in enumerate((8 * fx - 6, 16 * fx - 12, 24 * fx - 18, 4 * fx - 1, 12 * fx - 7) if fx in (16, 32) else
-                            (8 * fx - 4, 16 * fx - 8, 24 * fx - 12, 8 * fx - 5) if fx in (24, 40, 48) else
+    for k, bit in enumerate((8 * fx - 6, 16 * fx - 12, 24 * fx - 18, 4 * fx - 1, 12 * fx - 7) if fx in (16, 24, 32) else
+                            (8 * fx - 4, 16 * fx - 8, 24 * fx - 12, 8 * fx - 5) if fx in (40, 48) else
                             (16 * fx - 1, 16 * fx - 3, 8 * fx - 1, 24 * fx - 4)):
         vals[15 + 2 * k] = 2 ** bit - 2 ** fb if bit < fb else 2 ** (bit - 1)
         vals[16 + 2 * k] = 2 ** bit - 2 ** fb - 1 if bit < fb else -(2 ** (bit - 1))

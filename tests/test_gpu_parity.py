@@ -98,7 +98,7 @@ def test_precision_beyond_the_compiled_widths_is_a_clear_error():
                                                         # k_syrk_fx3 (32 x 32 tiles, 2 x 2 outputs per lane): odd widths (pair loads at
                                                         # 8-byte alignment, second column of the last pair past N), every quadrant mask
                                                         (512, 200, 81, None), (512, 333, 113, "3"), (400, 70, 47, None), (512, 90, 96, "2"),
-                                                        (1024, 100, 81, None), (1024, 150, 47, "3")])
+                                                        (1024, 100, 81, None), (1024, 150, 47, "3"), (768, 120, 81, None), (664, 90, 49, "2")])
 def test_int_syrk_bit_exact(precision, rows, cols, splits, monkeypatch):
     from oracle.oracle import Oracle
     if splits:
