@@ -3791,6 +3791,34 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
     }
 }
 
+// The row splits of k_syrk_fx3 added in place (into the planes of split 0), one lane per (product, output element): the
+// 16 x 105 planes of C4 read once by 21 x N^2 / 2 lanes at full occupancy instead of by the N^2 / 2 lanes of
+// k_syrk4_finish with their 196 registers (that kernel alone took 3.98 ms per launch with 16 splits; product + sum +
+// finish: 98.5 -> 95.6 ms); A3 limbs hold the sum over ALL rows (< 2^32 of them).
+template <int FX>
+__global__ void __launch_bounds__(WG) k_syrk3_sum_splits(uint32_t *part, int nsplit, size_t acc_stride, int N, size_t idx0, size_t idx1)
+{
+  constexpr int M3 = FX / 8, A3 = 2 * M3 + 1;
+  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
+  const int prod = blockIdx.y;
+  if(idx >= idx1 || (int)(idx % N) < (int)(idx / N))
+    return;
+  uint32_t out[A3];
+  uint64_t cy = 0;
+#pragma unroll
+  for(int k = 0; k < A3; ++k)
+    {
+#pragma unroll 8
+      for(int s = 0; s < nsplit; ++s)
+        cy += part[(((size_t)s * 21 + prod) * A3 + k) * acc_stride + idx];
+      out[k] = (uint32_t)cy;
+      cy >>= 32;
+    }
+#pragma unroll
+  for(int k = 0; k < A3; ++k)
+    part[((size_t)prod * A3 + k) * acc_stride + idx] = out[k];
+}
+
 template <int FX> constexpr int syrk_waves_per_simd() { return fx_toom4k<FX>() ? SDPB_SYRK3_WAVES : SDPB_SYRK_WAVES; }
 
 // Remove the bias in place (after any cross-GPU sum): for i >= j

@@ -1703,7 +1703,14 @@ private:
         else
         launch(k_syrk_fx2<FX, SYRK_RB, true>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out,
                acc_stride, tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
-        launch(k_syrk4_finish<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, (const uint32_t *)toomU, acc,
+        int nsum = nsplit;
+        if constexpr(SYRK_TOOM4K)
+          if(nsplit > 1)
+            {
+              launch(k_syrk3_sum_splits<FX>, dim3(cdiv(idx1 - idx0, WG), 21), dim3(WG), stream_, part.p, nsplit, acc_stride, N, idx0, idx1);
+              nsum = 1;
+            }
+        launch(k_syrk4_finish<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsum, (const uint32_t *)toomU, acc,
                acc_stride, N, idx0, idx1);
         return;
       }
