@@ -1,7 +1,7 @@
 #!/bin/bash
 # final build of round 4: simulated ranks (planning aid), the other workloads, shared-GPU RCCL bench lines
 set +e
-O=gpurun_out/r04n; mkdir -p $O
+O=gpurun_out/${1:-r04n}; mkdir -p $O
 export TMPDIR=/tmp
 for w in 2 4 8; do
   timeout 600 python bench.py --simulate-world $w --steps 10 --warmup 3 --no-cpu-baseline > $O/sim_world${w}.json 2>> $O/err.log

@@ -13,7 +13,8 @@ for v in sdpb_amd/_variants/*.so; do
 import json,sys
 try:
     d=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{"metric"')][-1]
-    print(sys.argv[1].split('/')[-1], d.get("value"), d.get("ms_per_step"), "syrk", d["roofline"].get("launch_ms"), "macfrac", d["roofline"].get("limb_mac_frac_of_measured_valu_peak"), (d.get("parity_gate") or {}).get("worst_log2_rel"), (d.get("parity_gate") or {}).get("passed"))
+    st=d.get("stage_ms_profiled_iteration",{})
+    print(sys.argv[1].split('/')[-1], d.get("value"), d.get("ms_per_step"), "trsm", st.get("initializeSchurComplementSolver.Q.solve"), "chol", st.get("choleskyDecomposition"), "pred", st.get("computeSearchDirection(betaPredictor)"), "syrk", d["roofline"].get("launch_ms"), "macfrac", d["roofline"].get("limb_mac_frac_of_measured_valu_peak"), (d.get("parity_gate") or {}).get("worst_log2_rel"), (d.get("parity_gate") or {}).get("passed"))
 except Exception as e: print(sys.argv[1], "unreadable", e)
 PY
 done

@@ -525,6 +525,14 @@ constexpr int TR = WG / PB;
 #define SDPB_TRSM_KC 4
 #endif
 constexpr int TRSM_KC = PB < SDPB_TRSM_KC ? PB : SDPB_TRSM_KC; // columns per LDS-staged operand chunk of the panel kernels
+#ifndef SDPB_TRSM_ALIAS
+#define SDPB_TRSM_ALIAS 1 // measured on C4 (profiles/r04t_trsm_variants.txt): P = L^-1 B 35.1 -> 34.1 ms, 34.8 -> 34.4 / 34.1 ms on another box
+#endif
+// ... of the two Cholesky panel kernels (k_chol_panel_solve, chol_syrk_tile): half the barriers per term
+#ifndef SDPB_CHOL_KC
+#define SDPB_CHOL_KC SDPB_TRSM_KC
+#endif
+constexpr int CHOL_KC = PB < SDPB_CHOL_KC ? PB : SDPB_CHOL_KC;
 
 // Cholesky panel solve: A(r, panel p) := A(r, panel p) * Li_pp^T for the rows below the
 // diagonal block, and zero the part of the panel above it.   grid = (row tiles, batch)
@@ -532,7 +540,7 @@ constexpr int TRSM_KC = PB < SDPB_TRSM_KC ? PB : SDPB_TRSM_KC; // columns per LD
 // The rows of the tile and chunks of KC columns of Li are staged in limb-major LDS.
 template <int NL> __global__ void __launch_bounds__(WG) k_chol_panel_solve(Batch A, Batch Li, int p, int tile0, unsigned long long *cyc)
 {
-  constexpr int KC = TRSM_KC, SLN = PB * KC, STN = TR * PB;
+  constexpr int KC = CHOL_KC, SLN = PB * KC, STN = TR * PB;
   const int q = blockIdx.y;
   WgClock clk(cyc, q);
   const MatDesc d = A.d[q], di = Li.d[q];
@@ -645,7 +653,7 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_syrk_cols(Batch A
 }
 template <int NL> __device__ void chol_syrk_tile(const Batch &A, const MatDesc &d, int k0, int nb, int b0, int M, int ti, int tj, int cmin, int cmax)
 {
-  constexpr int KC = TRSM_KC, SN = 16 * KC;
+  constexpr int KC = CHOL_KC, SN = 16 * KC;
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
   const int i = ti * 16 + li, j = tj * 16 + lj;
   const bool ok = i < M && j <= i && j >= cmin && j < cmax;
@@ -814,7 +822,14 @@ MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const 
                          uint32_t *smem)
 {
   constexpr int KC = TRSM_KC, ROWS = WG / COLS, SXN = ROWS * KC, SLN = COLS * KC, STN = ROWS * COLS;
+#if SDPB_TRSM_ALIAS
+  // the T tile of the second phase lies over the X chunk of the first (whose last pass ends with a barrier): 384
+  // instead of 416 numbers of LDS per workgroup = five workgroups per CU instead of four
+  static_assert(SXN <= STN, "the X chunk fits under the T tile");
+  uint32_t *st = smem, *sx = smem, *sl = smem + (NL + 2) * STN;
+#else
   uint32_t *sx = smem, *sl = sx + (NL + 2) * SXN, *st = sl + (NL + 2) * SLN;
+#endif
   if((int)(blockIdx.x * ROWS) >= dx.rows)
     return;
   const int rl = threadIdx.x % ROWS, j = threadIdx.x / ROWS;
@@ -882,7 +897,11 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
   const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
   // X chunk + L chunk + T tile: (WG/COLS + COLS) KC + WG numbers, largest at COLS = PB and COLS = 8
   constexpr int MINC = PB < 8 ? PB : 8, NMAX = (WG / MINC + MINC) * KC > (WG / PB + PB) * KC ? (WG / MINC + MINC) * KC : (WG / PB + PB) * KC;
+#if SDPB_TRSM_ALIAS
+  __shared__ uint32_t smem[(NL + 2) * (WG + PB * KC)];
+#else
   __shared__ uint32_t smem[(NL + 2) * (NMAX + WG)];
+#endif
   if constexpr(PB >= 32)
     {
       if(nb <= 8)
@@ -903,7 +922,14 @@ MW_HD void trsm_rln_tile(const Batch &L, const Batch &Li, const Batch &X, const 
                          uint32_t *smem)
 {
   constexpr int KC = TRSM_KC, ROWS = WG / COLS, SXN = ROWS * KC, SLN = COLS * KC, STN = ROWS * COLS;
+#if SDPB_TRSM_ALIAS
+  // the T tile of the second phase lies over the X chunk of the first (whose last pass ends with a barrier): 384
+  // instead of 416 numbers of LDS per workgroup = five workgroups per CU instead of four
+  static_assert(SXN <= STN, "the X chunk fits under the T tile");
+  uint32_t *st = smem, *sx = smem, *sl = smem + (NL + 2) * STN;
+#else
   uint32_t *sx = smem, *sl = sx + (NL + 2) * SXN, *st = sl + (NL + 2) * SLN;
+#endif
   if((int)(blockIdx.x * ROWS) >= dx.rows)
     return;
   const int n = dl.rows;
@@ -970,7 +996,11 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rln_panel(Batch L
     return;
   const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
   constexpr int MINC = PB < 8 ? PB : 8, NMAX = (WG / MINC + MINC) * KC > (WG / PB + PB) * KC ? (WG / MINC + MINC) * KC : (WG / PB + PB) * KC;
+#if SDPB_TRSM_ALIAS
+  __shared__ uint32_t smem[(NL + 2) * (WG + PB * KC)];
+#else
   __shared__ uint32_t smem[(NL + 2) * (NMAX + WG)];
+#endif
   if constexpr(PB >= 32)
     {
       if(nb <= 8)
