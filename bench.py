@@ -25,7 +25,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-LIMB_MAC_PEAK = 17.0e12        # measured on MI355X: v_mad_u64_u32 + v_addc_co_u32 pairs/s (profiles/r01_ubench.txt)
+LIMB_MAC_PEAK = 19.3e12        # measured on MI355X: v_mad_u64_u32 + v_addc_co_u32 pairs/s at >= 2 wavefronts per SIMD (profiles/r04_ubench_macpairs.txt;
+                               # the 17.0e12 of profiles/r01_ubench.txt, used until the last build of round 4, came from a loop of 8 pairs per 19 instructions)
 
 
 def _probe_reference_binary():
