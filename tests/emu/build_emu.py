@@ -53,13 +53,15 @@ def _run(cmd):
         raise RuntimeError("emu build failed")
 
 
-VARIANTS = {"notoom4": (["-DSDPB_SYRK_NO_TOOM4"], (18,))}   # name -> (extra flags, limb counts): documented build options kept alive
+VARIANTS = {"notoom4": (["-DSDPB_SYRK_NO_TOOM4"], (18,)),    # name -> (extra flags, limb counts): documented build options kept alive
+            "notoom4k": (["-DSDPB_SYRK_NO_TOOM4K"], (18,))}
 
 
 def build(force=False, panel=None, variant=None):
     """panel=None: the product configuration; panel=4: same sources with 4-column panels so that
     even the small golden SDPs run through the multi-panel Cholesky / triangular-solve paths;
-    variant="notoom4": -DSDPB_SYRK_NO_TOOM4 (the two-level Karatsuba image at every precision)."""
+    variant="notoom4": -DSDPB_SYRK_NO_TOOM4 (the two-level Karatsuba image at every precision, INTEGRATION.md section 3);
+    variant="notoom4k": -DSDPB_SYRK_NO_TOOM4K (Toom-4 alone, k_syrk_fx2<.., true>, the 495-bit image of round 3)."""
     global OUT, LIB
     base_out = os.path.join(HERE, "_build")
     OUT = base_out if panel is None else os.path.join(base_out, f"pb{panel}")

@@ -145,6 +145,26 @@ def test_chased_cholesky_Q_with_4_column_panels(name, limit, monkeypatch):
     assert traces[0] == traces[1]
 
 
+def test_documented_build_without_the_karatsuba_level_keeps_working():
+    """-DSDPB_SYRK_NO_TOOM4K (Toom-4 alone, the round-3 kernel k_syrk_fx2<16,32,toom4> and its
+    495-bit image at 512 bits) stays a working option: exact product incl. a width beyond one 16-column tile, and the Q stage."""
+    import random
+    from oracle.oracle import Oracle
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, 512, lib_path=libs.emu_lib(variant="notoom4k"))
+    assert s.limbs == 18 and s.fx_frac_bits == 32 * 16 - 17
+    o = Oracle(sdp, 512)
+    rng = random.Random(13)
+    rows, cols, fb = 41, 35, s.fx_frac_bits
+    vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
+    vals[3], vals[4], vals[5] = 2 ** fb - 1, -(2 ** fb) + 1, 0
+    got, want = s.op_int_syrk(rows, cols, vals), o.int_syrk(rows, cols, vals)
+    assert all(got[i + j * cols] == want[j + i * cols] for j in range(cols) for i in range(j, cols))
+    assert parity.check_syrk_Q(s, 512) <= -(512 - 40)
+    s.close()
+    o.close()
+
+
 def test_emulated_library_matches_oracle_on_dim6_blocks():
     """BASELINE.json config 5 shape (m_j = 6, K_j = 2: 21 (r,s) pairs per block) at reduced size
     and precision 512: exercises the (r,s) tile decoding of pairings, Schur assembly, constraint
