@@ -129,8 +129,10 @@ def cpu_baseline(cfg_name: str, precision: int, seconds_budget: float = 45.0, fu
     # the reference's algorithm for the same stage: full N, a row slice (linear in rows), primes for the FULL height
     P_full, N_full = sum(K * m * (m + 1) // 2 for m, K in zip(fullc["dims"], fullc["num_points"])), fullc["N"]
     rows = P_full if full else max(1, min(P_full, int(float(os.environ.get("SDPB_BENCH_REFQ_ROWS", "6000")))))
-    rq = ref_q.time_q_stage(rows, N_full, precision, P_full, threads=cores)
-    q_ref_full = rq["seconds"] * P_full / rows
+    # steps 2-4 all timed (round 5): residues and CRT compiled on GMP (oracle/sdpb_oracle.cpp), dsyrk through OpenBLAS; the
+    # residues and the dsyrk calls are linear in the rows and scaled, the CRT of the N (N + 1) / 2 outputs is run in full
+    rq = ref_q.time_q_stage_gmp(rows, N_full, precision, P_full, threads=cores)
+    q_ref_full = rq["seconds_linear_in_rows"] * P_full / rows + rq["crt_s"]
     t_ref = max(t_full - q_port_full, 0.0) + q_ref_full
     return {"value": 1.0 / t_full, "unit": "iterations/s", "cores": threads, "kind": "port",
             "extrapolation_factor": factor, "sample_iterations_per_s": 1.0 / dt,
@@ -138,9 +140,10 @@ def cpu_baseline(cfg_name: str, precision: int, seconds_budget: float = 45.0, fu
             "q_stage_port_s": q_port_full, "q_stage_reference_algorithm_s": q_ref_full,
             "q_stage_reference_algorithm": {**{k: (round(v, 3) if isinstance(v, float) else v) for k, v in rq.items()},
                                             "scaled_by_rows": P_full / rows,
-                                            "what": "oracle/bigint_syrk_blas.py: Fmpz_Comb primes, centred fp64 residues (one GEMM + "
-                                                    "remainder), one scipy.linalg.blas.dsyrk per prime at full N; CRT excluded "
-                                                    "(timed in pure Python only, see crt_python_one_thread_s_not_included)"},
+                                            "what": "oracle/bigint_syrk_blas.py + oracle/sdpb_oracle.cpp: Fmpz_Comb primes, centred "
+                                                    "residues by mpz_fdiv_ui per prime (OpenMP), one scipy.linalg.blas.dsyrk per prime at "
+                                                    "full N accumulated over row chunks, CRT of all N(N+1)/2 outputs by mpz_addmul_ui over "
+                                                    "the primes (OpenMP): the whole stage, crt_included"},
             "value_with_reference_q_stage": 1.0 / t_ref,
             "sample": probe_note + f"`value` = the PORT as measured: oracle (GMP mpf restatement, OpenMP over blocks/columns, "
                       f"{threads} threads on {cores} host cores) on {cfg_name} x{scale}: J={sdp.J}, N={sdp.N}, P_tot={sdp.P_total}; "
@@ -461,6 +464,22 @@ def main():
     t_setup = time.time()
     if sim:   # the faked exchange cannot supply the panels other ranks would factor
         os.environ["SDPB_HIP_DIST_CHOLQ"] = "0"
+    # Planned HBM footprint of this rank, BEFORE anything is allocated or uploaded (sdpb_amd/workmodel.py: the arrays of
+    # Solver::build_layout from the shapes alone): a plan that cannot fit fails here, on every rank, with the table --
+    # not minutes later inside an allocation (full C5 on fewer than four GPUs, say).
+    from sdpb_amd.solver import plan_blocks
+    owners = plan_blocks(sdp.dims, sdp.num_points, sdp.N, sim or world, lib_path=args.lib)
+    planned = workmodel.planned_footprint(sdp.dims, sdp.num_points, sdp.N, precision, owners, rank,
+                                          sim or world, dist_cholq=os.environ.get("SDPB_HIP_DIST_CHOLQ") == "1",
+                                          max_shared_bytes=int(float(os.environ.get("SDPB_HIP_SYRK_PART_BYTES", "0"))))
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    print(f"[bench rank {rank}/{world}] planned HBM footprint {planned['total'] / 1e9:.2f} GB of {total_b / 1e9:.0f} GB "
+          f"({free_b / 1e9:.0f} GB free): " + ", ".join(f"{k} {v / 1e9:.2f}" for k, v in planned.items()
+                                                        if k not in ("total", "rows", "owned_blocks")) +
+          f"; {planned['owned_blocks']} blocks, {planned['rows']} rows", file=sys.stderr, flush=True)
+    if planned["total"] > free_b and not share:
+        raise SystemExit(f"bench.py rank {rank}: the planned footprint {planned['total'] / 1e9:.1f} GB exceeds the {free_b / 1e9:.1f} GB free on "
+                         f"device {local_rank}: use more GPUs (--gpus) or a smaller workload")
     dog.enter("upload")
     solver = SDPSolver(sdp, precision, params, device=local_rank, rank=rank, world_size=sim or world, upload_all_blocks=False,
                        block_source=source, lib_path=args.lib)
@@ -600,6 +619,10 @@ def main():
     solver.set_profiling(False)
     dog.disarm()
 
+    try:
+        mem_plan = solver.memory_plan()
+    except AttributeError:   # --lib with a build older than round 5 (A/B timing only)
+        mem_plan = {"syrk": None, "bytes": {}, "device": None}
     if rank == 0:
         ms_per_step = 1000.0 * dt / args.steps
         value = args.steps / dt
@@ -676,7 +699,16 @@ def main():
                          "measured_copy_peak": copy_gbs,
                          "launch_ms": 1000.0 * k_avg_s, "algorithmic_bytes_per_launch": k_bytes,
                          "limb_mac_per_s": k_macs / k_avg_s if k_avg_s > 0 else 0.0,
-                         "limb_mac_frac_of_measured_valu_peak": (k_macs / k_avg_s / LIMB_MAC_PEAK) if k_avg_s > 0 else 0.0},
+                         "limb_mac_frac_of_measured_valu_peak": (k_macs / k_avg_s / LIMB_MAC_PEAK) if k_avg_s > 0 else 0.0,
+                         # how the launch was cut (solver.hpp: syrk_plan): output tiles per chunk under the memory bound, row
+                         # splits per tile and their length -- above P_tot = 81 920 rows the "<= 2560 rows per split" rule that
+                         # keeps the operand panels in L2 stops holding (32 splits at most) and this shows it
+                         "syrk_plan": mem_plan["syrk"],
+                         # fraction bits of the fixed-point image of P' the exact integer product is formed from, beside the
+                         # reference's (Matrix_Normalizer.cxx:174-192 truncates at 2^precision)
+                         "q_image_bits": solver.fx_frac_bits, "reference_bits": precision},
+            "memory_plan": {"bytes": mem_plan["bytes"], "total_GB": round(sum(mem_plan["bytes"].values()) / 1e9, 2),
+                            "planned_before_upload_GB": round(planned["total"] / 1e9, 2), "device": mem_plan["device"]},
             "algorithmic_bytes_per_iteration": workmodel.algorithmic_bytes_per_iteration(
                 sdp.dims, sdp.num_points, sdp.N, 4 * (nl + 1)),
             "stage_ms_profiled_iteration": stages,

@@ -201,6 +201,20 @@ int sdpb_hip_rccl_preflight(const char id[SDPB_HIP_RCCL_ID_BYTES], int rank, int
  * PrimalStepTooSmall; with several ranks every rank follows rank 0's clock (":66-69").
  * The clock starts at the first sdpb_hip_iterate after sdpb_hip_init_state. */
 int sdpb_hip_set_max_runtime(sdpb_hip_ctx *ctx, double seconds);
+/* --maxSharedMemory (src/sdpb/SDPB_Parameters, consumed in SDP_Solver::run: run.cxx:79-181 sizes the shared-memory
+ * windows of the Q stage with it, BigInt_Shared_Memory_Syrk_Context.cxx:149-215 splits the output into windows that
+ * fit, bigint_syrk_blas.cxx:200-220 loops over them).  Here the stage's scratch is the partial planes of the exact
+ * integer syrk (row splits x limb planes x tile-packed lower triangle of Q'): when they exceed `bytes` Q' is computed
+ * in chunks of output tiles that fit -- bit-identical results, the chunks only reuse one bounded buffer.  0 = default:
+ * what is free on the device when the solver is created, minus a reserve, at most 1/8 of the device.  May be called any
+ * time between iterations.  (Environment override for tests and GPUs shared by several ranks: SDPB_HIP_SYRK_PART_BYTES.) */
+int sdpb_hip_set_max_shared_memory(sdpb_hip_ctx *ctx, unsigned long long bytes);
+/* The rank's memory plan as a JSON object: bytes per array class ("bytes": psd_state_and_scratch, bases_and_pairings,
+ * schur_blocks, B, P, P_fixed_point_image, Q, syrk_partial_planes, vectors_and_small), the syrk plan ("syrk": tiles,
+ * chunks, tiles_per_chunk, row_splits, rows_per_split, partial_bytes, partial_bytes_unbounded, budget_bytes and where
+ * the budget comes from) and the device's free/total bytes -- what the reference prints at --verbosity 2 from
+ * run.cxx:79-181 (its memory estimates per node).  Same calling convention as sdpb_hip_timers. */
+int sdpb_hip_memory_plan(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed);
 /* Graceful stop (run.cxx:332-355): async-signal-safe, may be called from a SIGTERM handler
  * on any rank; the next sdpb_hip_iterate of EVERY rank returns terminated with reason
  * "SIGTERM signal received" and leaves x, X, y, Y untouched for the checkpoint. */

@@ -146,6 +146,108 @@ def int_syrk(values_colmajor: Sequence[int], rows: int, cols: int, value_bits: i
     return out
 
 
+# ---- steps 2 and 4 compiled, on GMP (oracle/sdpb_oracle.cpp: orc_refq_residues, orc_refq_crt) -------------------------
+def _lib():
+    import ctypes
+    from oracle.oracle import lib
+    L = lib()
+    if not getattr(L, "_refq_ready", False):
+        ulp = ctypes.POINTER(ctypes.c_ulong)
+        L.orc_refq_residues.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_ulong, ctypes.c_ulong, ulp, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        L.orc_refq_crt.argtypes = [ctypes.c_void_p, ctypes.c_long, ulp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                   ctypes.POINTER(ctypes.c_size_t), ulp, ctypes.POINTER(ctypes.c_double)]
+        L._refq_ready = True
+    return L
+
+
+def residues_gmp(values: Sequence[int] | None, count: int, bits: int, primes: Sequence[int], seed: int = 7, first: int = 0):
+    """Step 2 with mpz_fdiv_ui per (entry, prime), OpenMP over entries (orc_set_threads / $ORACLE_THREADS).
+    values None: `count` pseudo-random entries |v| < 2^bits generated inside (not timed).  -> ((primes, count) float64, seconds)."""
+    import ctypes
+    L = _lib()
+    out = np.empty((len(primes), count), dtype=np.float64)
+    pr = (ctypes.c_ulong * len(primes))(*primes)
+    sec = ctypes.c_double(0.0)
+    txt = None if values is None else " ".join(str(int(v)) for v in values).encode()
+    rc = L.orc_refq_residues(txt, count, bits, seed, first, pr, len(primes), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(sec))
+    if rc:
+        raise RuntimeError(f"orc_refq_residues failed ({rc})")
+    return out, sec.value
+
+
+def crt_gmp(prod: np.ndarray, primes: Sequence[int], want_values: bool = False):
+    """Step 4: prod (primes, n) float64 exact integers -> (list of n Python ints or None, seconds, checksum);
+    mpz_addmul_ui over the primes + one mpz_fdiv_r per output, OpenMP over outputs."""
+    import ctypes
+    L = _lib()
+    prod = np.ascontiguousarray(prod, dtype=np.float64)
+    n = prod.shape[1]
+    pr = (ctypes.c_ulong * len(primes))(*primes)
+    sec, chk, need = ctypes.c_double(0.0), ctypes.c_ulong(0), ctypes.c_size_t(0)
+    buf = ctypes.create_string_buffer(n * (int(sum(math.log10(p) for p in primes)) + 4) + 16) if want_values else None
+    rc = L.orc_refq_crt(prod.ctypes.data_as(ctypes.c_void_p), n, pr, len(primes), buf, len(buf) if buf else 0,
+                        ctypes.byref(need) if want_values else None, ctypes.byref(chk), ctypes.byref(sec))
+    if rc:
+        raise RuntimeError(f"orc_refq_crt failed ({rc})")
+    vals = [int(t) for t in buf.value.decode().split()] if want_values else None
+    return vals, sec.value, chk.value
+
+
+def int_syrk_gmp(values_colmajor: Sequence[int], rows: int, cols: int, value_bits: int) -> List[List[int]]:
+    """int_syrk with the compiled steps 2 and 4 (small sizes: tests)."""
+    primes = calculate_primes(output_bits(value_bits, value_bits, rows), rows)
+    rowmajor = [values_colmajor[r + c * rows] for r in range(rows) for c in range(cols)]
+    res, _ = residues_gmp(rowmajor, rows * cols, value_bits, primes)
+    prod = syrk_residues(res, rows, cols)
+    tri = [(i, j) for i in range(cols) for j in range(i + 1)]
+    flat = np.stack([np.array([prod[q, i, j] for i, j in tri]) for q in range(len(primes))])
+    vals, _, _ = crt_gmp(flat, primes, want_values=True)
+    out = [[0] * cols for _ in range(cols)]
+    for (i, j), v in zip(tri, vals):
+        out[i][j] = v
+    return out
+
+
+def time_q_stage_gmp(rows: int, cols: int, precision: int, total_rows: int, seed: int = 7, threads: int = 0,
+                     chunk_rows: int = 4000) -> dict:
+    """Wall time of the WHOLE stage, steps 2-4, the reference's way: residues on GMP (compiled, all threads), one dsyrk per
+    prime on a multi-threaded OpenBLAS (accumulated over row chunks, beta = 1: the sums of `total_rows` centred residue
+    products stay below 2^53 by the choice of the primes), CRT on GMP for all cols (cols + 1) / 2 outputs.  Steps 2 and 3
+    are exactly linear in the rows (`rows` of `total_rows` are run, the caller scales); step 4 does not depend on them."""
+    import os
+    from scipy.linalg.blas import dsyrk
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                      # pragma: no cover
+        from contextlib import contextmanager
+
+        @contextmanager
+        def threadpool_limits(limits=None):
+            yield
+    from oracle.oracle import lib
+    threads = lib().orc_set_threads(int(threads or len(os.sched_getaffinity(0))))
+    primes = calculate_primes(output_bits(precision, precision, total_rows), total_rows)
+    acc = [np.zeros((cols, cols), dtype=np.float64, order="F") for _ in primes]
+    t_res = t_syrk = 0.0
+    for r0 in range(0, rows, chunk_rows):
+        nr = min(chunk_rows, rows - r0)
+        res, sec = residues_gmp(None, nr * cols, precision, primes, seed, first=r0 * cols)
+        t_res += sec
+        t1 = time.perf_counter()
+        with threadpool_limits(limits=threads):
+            for q in range(len(primes)):
+                a = res[q].reshape(nr, cols)        # C-contiguous rows x cols == Fortran cols x rows: A^T
+                acc[q] = dsyrk(1.0, a.T, beta=1.0, c=acc[q], trans=0, lower=1, overwrite_c=1)
+        t_syrk += time.perf_counter() - t1
+    iu = np.tril_indices(cols)
+    flat = np.stack([a[iu] for a in acc])
+    _, t_crt, chk = crt_gmp(flat, primes)
+    return {"primes": len(primes), "prime_bits": round(math.log2(primes[0]), 2), "rows": rows, "cols": cols, "threads": threads,
+            "residues_s": t_res, "dsyrk_s": t_syrk, "crt_s": t_crt, "crt_outputs": int(flat.shape[1]), "crt_included": True,
+            "seconds_linear_in_rows": t_res + t_syrk, "checksum": chk}
+
+
 def time_q_stage(rows: int, cols: int, precision: int, total_rows: int, seed: int = 7, crt_sample: int = 2000,
                  threads: int = 0) -> dict:
     """Wall time of steps 2-4 for a rows x cols slice of a P' with `total_rows` rows in all (the primes depend on

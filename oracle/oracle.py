@@ -176,6 +176,13 @@ class Oracle:
         self.L.orc_get_records(self.h, which.encode(), j, parity, limbs64, out.ctypes.data_as(ctypes.c_void_p), n)
         return out
 
+    def set_records(self, which: str, recs, j: int = 0, parity: int = 0):
+        """Bit-exact restore of x, X, y or Y from what records() returned (same precision, limbs64 wide enough)."""
+        import numpy as np
+        recs = np.ascontiguousarray(recs, dtype=np.uint64)
+        self.L.orc_set_records.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
+        self._chk(self.L.orc_set_records(self.h, which.encode(), j, parity, recs.shape[1] - 2, recs.ctypes.data_as(ctypes.c_void_p), recs.shape[0]))
+
     def schur_solver_init(self):
         """L_j, P_j, Cholesky(Q) from the current X, Y (approx_objective/setup_solver.cxx:204-220)."""
         self._chk(self.L.orc_schur_solver_init(self.h))

@@ -1890,6 +1890,42 @@ long orc_get_records(void *h, const char *which, int j, int parity, int limbs64,
   return (long)v.size();
 }
 
+// The inverse of orc_get_records for the solver state (x, X, y, Y): bit-exact restore of a state saved as records
+// (the generator of the full-size fixtures continues an interrupted run of hours from it:
+// tests/golden/synthetic/make_synthetic_golden.py).  A record must fit the mpf_t's allocation (_mp_prec + 1 limbs), which
+// it does when it was written by an oracle of the same precision with limbs64 >= that count.
+int orc_set_records(void *h, const char *which, int j, int parity, int limbs64, const uint64_t *in, long count)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  ORC_TRY(o)
+  const std::string w(which);
+  std::vector<F> *dst = nullptr;
+  if(w == "y") dst = &o->y;
+  else
+    {
+      Block &bl = o->blk.at(j);
+      if(w == "x") dst = &bl.x;
+      else if(w == "X") dst = &bl.X[parity ? 1 : 0].a;
+      else if(w == "Y") dst = &bl.Y[parity ? 1 : 0].a;
+      else throw std::runtime_error("orc_set_records: unknown array " + w);
+    }
+  if((long)dst->size() != count)
+    throw std::runtime_error("orc_set_records: wrong element count for " + w);
+  for(long i = 0; i < count; ++i)
+    {
+      const uint64_t *rec = in + (size_t)i * (size_t)(limbs64 + 2);
+      F &f = (*dst)[(size_t)i];
+      const long size = (long)(long long)rec[0], n = size < 0 ? -size : size;
+      if(n > limbs64 || n > (long)f.v->_mp_prec + 1)
+        throw std::runtime_error("orc_set_records: a record is wider than the oracle's mantissa");
+      for(long k = 0; k < n; ++k)
+        f.v->_mp_d[k] = rec[2 + k];
+      f.v->_mp_size = (int)size;
+      f.v->_mp_exp = (mp_exp_t)(long long)rec[1];
+    }
+  ORC_CATCH(o)
+}
+
 // ---- kernel-level oracles (calculate_matrix_square.test.cxx recipe) --------
 // Exact integer syrk: inputs are P' as decimal *integers* (rows x cols,
 // column-major), output upper triangle of Q' = P'^T P' as decimal integers
@@ -1956,5 +1992,151 @@ const char *orc_scalar_op(void *h, const char *op, const char *a, const char *b)
   else if(s == "sqrt") r = fsqrt(x);
   o->strbuf = to_str(r);
   return o->strbuf.c_str();
+}
+
+// ---------------------------------------------------------------------------
+// Steps 2 and 4 of the reference's OWN algorithm for Q' = P'^T P' on GMP (CPU-baseline leg of bench.py; the
+// description and step 3, one dsyrk per prime, are in oracle/bigint_syrk_blas.py):
+//   step 2  compute_block_residues.cxx:223-330 (_fmpz_multi_mod_precomp / fmpz_get_nmod, fmpz_mul_blas_util.hxx:71,84):
+//           every entry of P' modulo every prime, centred, as fp64 -- here mpz_fdiv_ui per (entry, prime), OpenMP over entries
+//   step 4  restore_bigint_from_residues.hxx:28 (fmpz_multi_CRT_ui, sign = 1), restore_and_reduce.cxx:64-77, the comb of
+//           fmpz/Fmpz_Comb.cxx:75-109: x = sum_q (r_q mod p_q) C_q mod M, C_q = (M / p_q) ((M / p_q)^-1 mod p_q), the
+//           representative of smallest magnitude -- here mpz_addmul_ui over the primes, one mpz_fdiv_r, OpenMP over outputs
+// FLINT's versions use remainder / product trees; these are the plain compiled forms of the same maps.
+// ---------------------------------------------------------------------------
+// txt != nullptr: `count` decimal integers (exactness tests); else the pseudo-random entries first ... first + count of a
+// stream |v| < 2^bits fixed by `seed` (generated before the clock starts).  out: np x count doubles.  seconds: wall time of the reduction alone.
+int orc_refq_residues(const char *txt, long count, int bits, unsigned long seed, unsigned long first, const unsigned long *primes, int np,
+                      double *out, double *seconds)
+{
+  try
+    {
+      std::vector<Z> v((size_t)count);
+      if(txt)
+        {
+          std::istringstream in(txt);
+          std::string tok;
+          for(auto &z : v)
+            {
+              if(!(in >> tok) || mpz_set_str(z.v, tok.c_str(), 10) != 0)
+                return 4;
+            }
+        }
+      else
+        {
+          // counter-based: entry (first + i) is the same number whatever the chunking and the thread count
+          const int nl = (bits + 63) / 64;
+#pragma omp parallel for schedule(static)
+          for(long i = 0; i < count; ++i)
+            {
+              uint64_t limb[64];
+              for(int k = 0; k < nl && k < 64; ++k)
+                {
+                  uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)(first + (unsigned long)i) * 64u + (uint64_t)k + 1u);
+                  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                  limb[k] = z ^ (z >> 31);
+                }
+              if(bits % 64)
+                limb[nl - 1] &= (~0ull) >> (64 - bits % 64);
+              mpz_import(v[(size_t)i].v, (size_t)nl, -1, 8, 0, 0, limb);
+              if(limb[0] & 1u)
+                mpz_neg(v[(size_t)i].v, v[(size_t)i].v);
+            }
+        }
+      const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(static)
+      for(long i = 0; i < count; ++i)
+        for(int q = 0; q < np; ++q)
+          {
+            const unsigned long p = primes[q];
+            const unsigned long r = mpz_fdiv_ui(v[(size_t)i].v, p); // in [0, p), sign respected (floor division)
+            out[(size_t)q * (size_t)count + (size_t)i] = r > p / 2 ? (double)r - (double)p : (double)r;
+          }
+      if(seconds)
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      return 0;
+    }
+  catch(...)
+    {
+      return 4;
+    }
+}
+// prod: np x n doubles (exact integers: the dsyrk sums of centred residues).  txt_out != nullptr: the n results as decimal
+// integers separated by newlines (tests); always: xor of the low limbs of all results in *checksum (keeps the work alive).
+int orc_refq_crt(const double *prod, long n, const unsigned long *primes, int np, char *txt_out, size_t txt_cap, size_t *needed,
+                 unsigned long *checksum, double *seconds)
+{
+  try
+    {
+      Z M;
+      mpz_set_ui(M.v, 1);
+      for(int q = 0; q < np; ++q)
+        mpz_mul_ui(M.v, M.v, primes[q]);
+      std::vector<Z> C((size_t)np);
+      for(int q = 0; q < np; ++q)
+        {
+          Z Mq, inv, pq;
+          mpz_divexact_ui(Mq.v, M.v, primes[q]);
+          mpz_set_ui(pq.v, primes[q]);
+          if(!mpz_invert(inv.v, Mq.v, pq.v))
+            return 4;
+          mpz_mul(C[(size_t)q].v, Mq.v, inv.v);
+        }
+      Z half;
+      mpz_fdiv_q_2exp(half.v, M.v, 1);
+      std::vector<Z> res(txt_out ? (size_t)n : 0);
+      unsigned long sum = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel reduction(^ : sum)
+      {
+        Z x;
+#pragma omp for schedule(static)
+        for(long i = 0; i < n; ++i)
+          {
+            mpz_set_ui(x.v, 0);
+            for(int q = 0; q < np; ++q)
+              {
+                const long long p = (long long)primes[q];
+                long long r = (long long)prod[(size_t)q * (size_t)n + (size_t)i] % p; // |prod| < 2^53: exact
+                if(r < 0)
+                  r += p;
+                mpz_addmul_ui(x.v, C[(size_t)q].v, (unsigned long)r);
+              }
+            mpz_fdiv_r(x.v, x.v, M.v);
+            if(mpz_cmp(x.v, half.v) > 0)
+              mpz_sub(x.v, x.v, M.v);
+            sum ^= mpz_getlimbn(x.v, 0) * (mpz_size(x.v) ? 1ul : 0ul);
+            if(txt_out)
+              mpz_set(res[(size_t)i].v, x.v);
+          }
+      }
+      if(seconds)
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if(checksum)
+        *checksum = sum;
+      if(txt_out || needed)
+        {
+          std::string s;
+          for(auto &z : res)
+            {
+              char *t = mpz_get_str(nullptr, 10, z.v);
+              s += t;
+              s += "\n";
+              free(t);
+            }
+          if(needed)
+            *needed = s.size() + 1;
+          if(txt_out && txt_cap >= s.size() + 1)
+            std::memcpy(txt_out, s.c_str(), s.size() + 1);
+          else if(txt_out)
+            return 5;
+        }
+      return 0;
+    }
+  catch(...)
+    {
+      return 4;
+    }
 }
 } // extern "C"

@@ -372,11 +372,26 @@ int sdpb_hip_rccl_preflight(const char id[SDPB_HIP_RCCL_ID_BYTES], int rank, int
       a.upload(mine);
       g.alloc((size_t)world * n);
       m.alloc(n);
-      hipStream_t s1, s2;
-      hipEvent_t ev;
-      HIP_CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
-      HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      // released on every way out of this function (round-4 advisor: the early "return fail" paths leaked them)
+      struct Handles
+      {
+        hipStream_t s1 = nullptr, s2 = nullptr;
+        hipEvent_t ev = nullptr;
+        ~Handles()
+        {
+          if(ev)
+            (void)hipEventDestroy(ev);
+          if(s1)
+            (void)hipStreamDestroy(s1);
+          if(s2)
+            (void)hipStreamDestroy(s2);
+        }
+      } h;
+      HIP_CHECK(hipStreamCreateWithFlags(&h.s1, hipStreamNonBlocking));
+      HIP_CHECK(hipStreamCreateWithFlags(&h.s2, hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&h.ev, hipEventDisableTiming));
+      const hipStream_t s1 = h.s1, s2 = h.s2;
+      const hipEvent_t ev = h.ev;
       // 1. all-gather in rank order (result blocks, N-vectors)
       comm->allgather(a.p, g.p, n * 8, s1);
       HIP_CHECK(hipMemcpyAsync(all.data(), g.p, (size_t)world * n * 8, hipMemcpyDeviceToHost, s1));
@@ -418,9 +433,6 @@ int sdpb_hip_rccl_preflight(const char id[SDPB_HIP_RCCL_ID_BYTES], int rank, int
         }
       if(comm->async_error() != 0)
         return fail(nullptr, 3, "sdpb_hip_rccl_preflight: the communicator reports an asynchronous error");
-      (void)hipEventDestroy(ev);
-      (void)hipStreamDestroy(s1);
-      (void)hipStreamDestroy(s2);
       return 0;
     }
   catch(sdpb::SolverError &e)
@@ -435,6 +447,15 @@ int sdpb_hip_rccl_preflight(const char id[SDPB_HIP_RCCL_ID_BYTES], int rank, int
 int sdpb_hip_set_max_runtime(sdpb_hip_ctx *ctx, double seconds)
 {
   return guarded(ctx, [&] { ctx->solver->set_max_runtime(seconds); });
+}
+int sdpb_hip_set_max_shared_memory(sdpb_hip_ctx *ctx, unsigned long long bytes)
+{
+  return guarded(ctx, [&] { ctx->solver->set_max_shared_memory(bytes); });
+}
+int sdpb_hip_memory_plan(sdpb_hip_ctx *ctx, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] { ctx->strbuf = ctx->solver->memory_plan_json(); });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
 }
 void sdpb_hip_request_stop(sdpb_hip_ctx *ctx)
 {

@@ -818,9 +818,12 @@ template <int NL> __global__ void __launch_bounds__(WG) k_chol_strip_update(Batc
 // covers the panel's width: a ragged last panel of 8 columns is worked on by 32 rows x 8
 // columns instead of 8 rows x 32 columns with three quarters of the lanes idle).
 template <int NL, int COLS>
-MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const MatDesc &dl, const MatDesc &di, const MatDesc &dx, int k0, int nb,
-                         uint32_t *smem)
+MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const mw::CPtr &src, const MatDesc &dl, const MatDesc &di,
+                         const MatDesc &dx, int k0, int nb, uint32_t *smem)
 {
+  // src: where the right-hand sides of THIS panel's columns are read (the solved columns k < k0 always come from X): X
+  // itself for the in-place solve, or another array with X's descriptors -- P = L^{-1} B reads B and writes P, which
+  // saves the 3-GB device-to-device copy per iteration the in-place form needed in front of it (round 5)
   constexpr int KC = TRSM_KC, ROWS = WG / COLS, SXN = ROWS * KC, SLN = COLS * KC, STN = ROWS * COLS;
 #if SDPB_TRSM_ALIAS
   // the T tile of the second phase lies over the X chunk of the first (whose last pass ends with a barrier): 384
@@ -837,7 +840,7 @@ MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const 
   const bool ok = r < dx.rows && j < nb;
   Acc<NL> acc = mw::acc_zero<NL>();
   if(ok)
-    mw::acc_add(acc, mat_ld<NL>(X, dx, r, k0 + j));
+    mw::acc_add(acc, mw::load<NL>(src, (size_t)dx.off + (size_t)r + (size_t)(k0 + j) * dx.ld));
   for(int k = 0; k < k0; k += KC) // k0 is a multiple of PB, PB of KC
     {
       for(int e = threadIdx.x; e < SXN + SLN; e += WG)
@@ -885,7 +888,7 @@ MW_HD void trsm_rlt_tile(const Batch &L, const Batch &Li, const Batch &X, const 
   if(ok)
     mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
 }
-template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, int p, unsigned long long *cyc)
+template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L, Batch Li, Batch X, mw::CPtr src, int p, unsigned long long *cyc)
 {
   constexpr int KC = TRSM_KC;
   const int q = blockIdx.y;
@@ -905,11 +908,11 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
   if constexpr(PB >= 32)
     {
       if(nb <= 8)
-        return trsm_rlt_tile<NL, 8>(L, Li, X, dl, di, dx, k0, nb, smem);
+        return trsm_rlt_tile<NL, 8>(L, Li, X, src, dl, di, dx, k0, nb, smem);
       if(nb <= 16)
-        return trsm_rlt_tile<NL, 16>(L, Li, X, dl, di, dx, k0, nb, smem);
+        return trsm_rlt_tile<NL, 16>(L, Li, X, src, dl, di, dx, k0, nb, smem);
     }
-  trsm_rlt_tile<NL, PB>(L, Li, X, dl, di, dx, k0, nb, smem);
+  trsm_rlt_tile<NL, PB>(L, Li, X, src, dl, di, dx, k0, nb, smem);
 }
 // X := X L^{-1}, panel p (backward over panels):
 //   T = X(:,panel p) - X(:,cols >= k0+nb) L(rows >= k0+nb, panel p) ;  X(:,panel p) = T Li_pp
@@ -2722,6 +2725,22 @@ MW_HD void syrk_rows(const uint32_t (&sa)[PL * RB * 16], const uint32_t (&sb)[PL
   syrk_fold<M, 2 * M + 2>(acc, c, h);
 }
 
+// TILE-PACKED partial outputs (round 5).  Whenever the product kernels do not write G itself (row splits, the Toom
+// images) their output planes hold only the tiles of the launch: element (i, j) of tile t of the launch's tile list at
+//   t E E + (i - E ti) + (j - E tj) E        (E = syrk_tile_edge<FX>(), plane stride = ntile E E words)
+// -- half the words of the N x N planes of rounds 1-4 (only the lower triangle has tiles), and a launch over a SUBSET of
+// the tiles needs planes for that subset only: Solver::syrk_G walks the tile list in chunks whose planes fit a memory
+// budget (the reference bounds the same stage by looping over output windows: bigint_syrk_blas.cxx:200-220,
+// BigInt_Shared_Memory_Syrk_Context.cxx:149-215, --maxSharedMemory).  The finishing kernels run one lane per packed
+// word, find (i, j) through the tile list and drop what lies outside the lower triangle, N, or the columns [col0, col1).
+template <int E> MW_HD bool syrk_packed_decode(size_t pidx, const uint32_t *tile_list, int N, int col0, int col1, int &i, int &j)
+{
+  const uint32_t tt = tile_list[pidx / (size_t)(E * E)];
+  const int r = (int)(pidx % (size_t)(E * E));
+  i = (int)(tt >> 16) * E + r % E;
+  j = (int)(tt & 0xffffu) * E + r / E;
+  return i < N && j <= i && j >= col0 && j < col1;
+}
 // acc(i,j) (i >= j, tiles of 16x16) = G(i,j) = sum_r a'(r,i) a'(r,j), rows r in
 // [0, nrows).  fx element (r,n) at r*N + n.  acc element (i,j) at i + j*N in
 // a (2FX+2)-plane limb-major array of non-negative integers.  Row chunks of RB rows are
@@ -2772,8 +2791,9 @@ inline int syrk_row_splits(int ntile, unsigned nrows, int slots, int rb, unsigne
 template <int FX, int RB>
 __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   k_syrk_fx(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tile_list,
-            int ntile, int nsplit, unsigned rows_per_split)
+            int ntile, int nsplit, unsigned rows_per_split, int packed)
 {
+  // packed: acc is the tile-packed partial array (plane stride acc_stride = ntile 256), else G itself (i + j N)
   constexpr int M = FX / 2, A = 2 * M + 2, W = 2 * FX + 2, PL = fx_planes<FX>();
   // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch), so XCD x is given
   // the contiguous range [x*per, (x+1)*per) of the items (split, tile), tiles enumerated
@@ -2909,29 +2929,32 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
         w[k] = k < A ? ll[k < A ? k : 0] : 0u;
       add_shifted<W, A>(w, ss, 32 * M - 1, false);
       add_shifted<W, A>(w, hh, 64 * M - 2, false);
-      const size_t o = (size_t)i + (size_t)j * N;
+      const size_t o = packed ? (size_t)tile * 256 + threadIdx.x : (size_t)i + (size_t)j * N;
 #pragma unroll
       for(int k = 0; k < W; ++k)
         acc[(size_t)k * acc_stride + o] = w[k];
     }
 }
 
-// acc(i,j) = sum over the row splits of part[split](i,j)  (i >= j)
-// [idx0, idx1): the entries (column-major, idx = i + j N) the launch covers -- whole columns of the output; the chunked
+// acc(i,j) = sum over the row splits of part[split](i,j)  (i >= j); part tile-packed (syrk_packed_decode), one lane per
+// packed word of the launch's `total` = ntile E E.  [col0, col1): the columns of the output the launch covers -- the chunked
 // Q' (Solver::q_chase_) finishes, reduces and restores the left columns while the right ones are still being multiplied
 template <int FX>
-__global__ void __launch_bounds__(WG) k_syrk_reduce(const uint32_t *part, int nsplit, uint32_t *acc, size_t acc_stride, int N, size_t idx0, size_t idx1)
+__global__ void __launch_bounds__(WG) k_syrk_reduce(const uint32_t *part, int nsplit, size_t part_stride, const uint32_t *tile_list, size_t total,
+                                                    uint32_t *acc, size_t acc_stride, int N, int col0, int col1)
 {
   constexpr int W = 2 * FX + 2;
-  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= idx1 || (int)(idx % N) < (int)(idx / N))
+  const size_t pidx = (size_t)blockIdx.x * WG + threadIdx.x;
+  int i, j;
+  if(pidx >= total || !syrk_packed_decode<syrk_tile_edge<FX>()>(pidx, tile_list, N, col0, col1, i, j))
     return;
+  const size_t idx = (size_t)i + (size_t)j * N;
   uint64_t cy = 0;
 #pragma unroll
   for(int k = 0; k < W; ++k)
     {
       for(int s = 0; s < nsplit; ++s)
-        cy += part[((size_t)s * W + k) * acc_stride + idx];
+        cy += part[((size_t)s * W + k) * part_stride + pidx];
       acc[(size_t)k * acc_stride + idx] = (uint32_t)cy;
       cy >>= 32;
     }
@@ -3161,19 +3184,19 @@ __global__ void __launch_bounds__(WG)
     toomU[(size_t)(Z + k) * N + col] = t[k];
 }
 // acc(i,j) (i >= j) = G(i,j) = sum_r a'_ri a'_rj from the seven product sums the row splits of
-// k_syrk_fx2<FX, RBG, true> left in part (split s, group g, limb k at ((s 7 + g) A2 + k) acc_stride + idx):
+// k_syrk_fx2<FX, RBG, true> left in part (split s, group g, limb k at ((s 7 + g) A2 + k) part_stride + packed index):
 // add the splits, remove the bias of the two signed evaluation points, interpolate, recombine.
 template <int FX>
 __global__ void __launch_bounds__(WG)
-  k_syrk4_finish(const uint32_t *part, int nsplit, const uint32_t *toomU, uint32_t *acc, size_t acc_stride, int N, size_t idx0, size_t idx1)
+  k_syrk4_finish(const uint32_t *part, int nsplit, size_t part_stride, const uint32_t *tile_list, size_t total, const uint32_t *toomU,
+                 uint32_t *acc, size_t acc_stride, int N, int col0, int col1)
 {
   constexpr int M2 = FX / 4, A2 = 2 * M2 + 1, Z = 2 * M2 + 2, W = 2 * FX + 2, WB = toom_wb<FX>();
-  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
-  if(idx >= idx1)
+  const size_t pidx = (size_t)blockIdx.x * WG + threadIdx.x;
+  int i, j;
+  if(pidx >= total || !syrk_packed_decode<syrk_tile_edge<FX>()>(pidx, tile_list, N, col0, col1, i, j))
     return;
-  const int i = (int)(idx % N), j = (int)(idx / N);
-  if(i < j)
-    return;
+  const size_t idx = (size_t)i + (size_t)j * N;
   uint32_t w[7][Z];
   // GMP's order: w0 = f(0), w1 = f(-2), w2 = f(1), w3 = f(-1), w4 = f(2), w5 = 64 f(1/2), w6 = f(inf)
   constexpr int GRP[7] = {0, 4, 1, 2, 3, 5, 6};
@@ -3193,7 +3216,7 @@ __global__ void __launch_bounds__(WG)
               for(int k = 0; k < A3; ++k)
                 {
                   for(int s = 0; s < nsplit; ++s)
-                    cy += part[(((size_t)s * 21 + 3 * GRP[q] + u) * A3 + k) * acc_stride + idx];
+                    cy += part[(((size_t)s * 21 + 3 * GRP[q] + u) * A3 + k) * part_stride + pidx];
                   g3[u][k] = (uint32_t)cy;
                   cy >>= 32;
                 }
@@ -3218,7 +3241,7 @@ __global__ void __launch_bounds__(WG)
         {
           if(k < A2)
             for(int s = 0; s < nsplit; ++s)
-              cy += part[(((size_t)s * 7 + GRP[q]) * A2 + k) * acc_stride + idx];
+              cy += part[(((size_t)s * 7 + GRP[q]) * A2 + k) * part_stride + pidx];
           w[q][k] = (uint32_t)cy;
           cy >>= 32;
         }
@@ -3282,8 +3305,9 @@ __global__ void __launch_bounds__(WG)
 template <int FX, int RBG, bool TOOM = false>
 __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
   k_syrk_fx2(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
-             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, const uint32_t *zero_piece)
+             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, const uint32_t *zero_piece, int packed)
 {
+  // packed (always with TOOM): acc is the tile-packed partial array (plane stride acc_stride = ntile 256), else G itself
   // A2 limbs hold the sum of one second-level product over a split's rows: pieces < 2^(32 M2), fewer
   // than 2^32 rows, so the sum stays below 2^(64 M2 + 32)
   constexpr int M2 = FX / 4, M = FX / 2, A2 = 2 * M2 + 1, A = 2 * M + 2, W = 2 * FX + 2;
@@ -3459,7 +3483,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
     {
       if(i < N && j <= i)
         {
-          const size_t o = (size_t)i + (size_t)j * N;
+          const size_t o = (size_t)tile * 256 + threadIdx.x;
 #pragma unroll
           for(int g = 0; g < NG; ++g)
             if(g < ngs)
@@ -3494,7 +3518,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
         w[k] = k < A ? x[0][k < A ? k : 0] : 0u;
       add_shifted<W, A>(w, x[2], 32 * M - 3, false);
       add_shifted<W, A>(w, x[1], 64 * M - 6, false);
-      const size_t o = (size_t)i + (size_t)j * N;
+      const size_t o = packed ? (size_t)tile * 256 + threadIdx.x : (size_t)i + (size_t)j * N;
 #pragma unroll
       for(int k = 0; k < W; ++k)
         acc[(size_t)k * acc_stride + o] = w[k];
@@ -3813,7 +3837,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
           for(int k = 0; k < A3; ++k)
             g[k] = 0;
           syrk_fold<M3, A3>(g, cc[o], hh[o]);
-          const size_t at = (size_t)i + (size_t)j * N;
+          const size_t at = (size_t)tile * 1024 + (size_t)(li + 16 * (o & 1)) + (size_t)(lj + 16 * (o >> 1)) * 32; // tile-packed
 #pragma unroll
           for(int k = 0; k < A3; ++k)
             acc[(size_t)(prod * A3 + k) * acc_stride + at] = g[k];
@@ -3826,12 +3850,14 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
 // k_syrk4_finish with their 196 registers (that kernel alone took 3.98 ms per launch with 16 splits; product + sum +
 // finish: 98.5 -> 95.6 ms); A3 limbs hold the sum over ALL rows (< 2^32 of them).
 template <int FX>
-__global__ void __launch_bounds__(WG) k_syrk3_sum_splits(uint32_t *part, int nsplit, size_t acc_stride, int N, size_t idx0, size_t idx1)
+__global__ void __launch_bounds__(WG) k_syrk3_sum_splits(uint32_t *part, int nsplit, size_t part_stride, const uint32_t *tile_list, size_t total, int N,
+                                                         int col0, int col1)
 {
   constexpr int M3 = FX / 8, A3 = 2 * M3 + 1;
-  const size_t idx = idx0 + (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t pidx = (size_t)blockIdx.x * WG + threadIdx.x;
   const int prod = blockIdx.y;
-  if(idx >= idx1 || (int)(idx % N) < (int)(idx / N))
+  int i, j;
+  if(pidx >= total || !syrk_packed_decode<32>(pidx, tile_list, N, col0, col1, i, j))
     return;
   uint32_t out[A3];
   uint64_t cy = 0;
@@ -3840,13 +3866,13 @@ __global__ void __launch_bounds__(WG) k_syrk3_sum_splits(uint32_t *part, int nsp
     {
 #pragma unroll 8
       for(int s = 0; s < nsplit; ++s)
-        cy += part[(((size_t)s * 21 + prod) * A3 + k) * acc_stride + idx];
+        cy += part[(((size_t)s * 21 + prod) * A3 + k) * part_stride + pidx];
       out[k] = (uint32_t)cy;
       cy >>= 32;
     }
 #pragma unroll
   for(int k = 0; k < A3; ++k)
-    part[((size_t)prod * A3 + k) * acc_stride + idx] = out[k];
+    part[((size_t)prod * A3 + k) * part_stride + pidx] = out[k];
 }
 
 template <int FX> constexpr int syrk_waves_per_simd() { return fx_toom4k<FX>() ? SDPB_SYRK3_WAVES : SDPB_SYRK_WAVES; }
@@ -4004,33 +4030,50 @@ constexpr int TRI_T = SDPB_TRI_T;
 // (A two-level exact sum through a limb-major image, as in k_gemv_n, was measured here and is slower:
 // 4.74 instead of 4.61 ms per launch; every lane needs the result, and the kernel is bound by the
 // wavefront-instructions it issues, not by the depth of this tree.)
-template <int NL, int T> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, Mw<NL> *sm)
+// Round 5: every sum of the kernel has ONE shape whatever T is (round-4 advisor: lambda_min depended on the team width,
+// which is picked from the CU count and from how many matrices a rank owns, in its last bits): the dot products of a
+// Householder step are taken by the first TRI_V lanes (term k by lane k mod TRI_V, a tree over TRI_V leaves -- adding the
+// exact zeros of idle lanes changes nothing), and the team width of the row products depends on the row length only.
+// (Measured and dropped, profiles/r05_tridiag_lanes.txt: an odd word stride for the tree's LDS image -- Mw<18> is 20 words,
+// 32 lanes fall on 8 banks -- turns its 16-byte LDS accesses into 4-byte ones and costs 0.8 ms per iteration; the
+// conflicts it would remove are 19 M of 95 M LDS-active cycles summed over 256 CUs, i.e. LDS is busy 3 % of this kernel.)
+constexpr int TRI_V = 64;
+template <int NL> struct TriSlot
 {
+  Mw<NL> v;
+#ifdef SDPB_TRI_PAD
+  uint32_t pad[(sizeof(Mw<NL>) / 4) % 2 == 0 ? 1 : 2]; // the measured variant: odd stride in words
+#endif
+};
+template <int NL> __device__ Mw<NL> tri_reduce_sum(const Mw<NL> &v, TriSlot<NL> *sm)
+{
+  // v: the contributions of the lanes t < TRI_V (other lanes pass anything); every lane gets the sum
   const int t = threadIdx.x;
-  sm[t] = v;
+  if(t < TRI_V)
+    sm[t].v = v;
   __syncthreads();
-  for(int s = T / 2; s > 0; s >>= 1)
+  for(int s = TRI_V / 2; s > 0; s >>= 1)
     {
       if(t < s)
-        sm[t] = mw::add(sm[t], sm[t + s]);
+        sm[t].v = mw::add(sm[t].v, sm[t + s].v);
       __syncthreads();
     }
-  const Mw<NL> r = sm[0];
+  const Mw<NL> r = sm[0].v;
   __syncthreads();
   return r;
 }
-// T lanes per matrix: TRI_T where the matrices outnumber the workgroup slots of the chip (one rank, C4), 2 TRI_T / 4 TRI_T
-// where a rank owns so few that every matrix is resident anyway and the launch lasts as long as the Householder chain
-// of the largest one (a rank of an 8-GPU job: step lengths are then a chain that does not divide by the rank count).
-template <int NL, int T> __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TRI_WAVES : 1024 / T) k_tridiag(Batch A, Batch D, Batch E)
+// T lanes per matrix (64 ... 512), chosen per SIZE BUCKET of the batch and by how many matrices the rank owns (host:
+// Solver::enqueue_min_eigenvalues): blockIdx -> matrix through `ids`.  The bits of the result do not depend on T.
+template <int NL, int T>
+__global__ void __launch_bounds__(T, T <= 256 ? SDPB_TRI_WAVES : 1024 / T) k_tridiag(Batch A, Batch D, Batch E, const int *ids)
 {
-  const int q = blockIdx.x;
+  const int q = ids[blockIdx.x];
   const MatDesc d = A.d[q];
   const size_t od = (size_t)D.d[q].off, oe = (size_t)E.d[q].off;
   const int n = d.rows, t = threadIdx.x;
   if(n == 0)
     return;
-  __shared__ Mw<NL> sm[T];
+  __shared__ TriSlot<NL> sm[T];
   __shared__ Mw<NL> s_hinv;
   for(int i = n - 1; i >= 1; --i)
     {
@@ -4042,12 +4085,13 @@ template <int NL, int T> __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TR
           continue;
         }
       Acc<NL> hp = mw::acc_zero<NL>();
-      for(int k = t; k <= l; k += T)
-        {
-          const Mw<NL> a = mat_ld<NL>(A, d, i, k);
-          mw::acc_fma(hp, a, a);
-        }
-      const Mw<NL> h0 = tri_reduce_sum<NL, T>(mw::acc_result(hp), sm);
+      if(t < TRI_V)
+        for(int k = t; k <= l; k += TRI_V)
+          {
+            const Mw<NL> a = mat_ld<NL>(A, d, i, k);
+            mw::acc_fma(hp, a, a);
+          }
+      const Mw<NL> h0 = tri_reduce_sum<NL>(mw::acc_result(hp), sm);
       if(mw::is_zero(h0))
         {
           if(t == 0)
@@ -4087,12 +4131,11 @@ template <int NL, int T> __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TR
 #endif
       __syncthreads();
       const Mw<NL> hinv = s_hinv;
-      // e[j] = (A_sub u)_j / h with teams of G lanes per row j
+      // e[j] = (A_sub u)_j / h with teams of G lanes per row j; G from the row length alone (not from T)
       const int w = l + 1;
-      int G = T / w;
+      int G = 128 / w;
       G = G < 1 ? 1 : (G > 8 ? 8 : G);
       const int teams = T / G, g = t % G;
-      Mw<NL> fpart = mw::zero<NL>();
       for(int j0 = 0; j0 < w; j0 += teams)
         {
           const int j = j0 + t / G;
@@ -4103,20 +4146,23 @@ template <int NL, int T> __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TR
                 const Mw<NL> ajk = k <= j ? mat_ld<NL>(A, d, j, k) : mat_ld<NL>(A, d, k, j);
                 mw::acc_fma(acc, ajk, mat_ld<NL>(A, d, i, k));
               }
-          sm[t] = mw::acc_result(acc);
+          sm[t].v = mw::acc_result(acc);
           __syncthreads();
           if(g == 0 && j < w && t / G < teams)
             {
-              Mw<NL> sum = sm[t];
+              Mw<NL> sum = sm[t].v;
               for(int gg = 1; gg < G; ++gg)
-                sum = mw::add(sum, sm[t + gg]);
-              const Mw<NL> ej = mw::mul(sum, hinv);
-              mw::store<NL>(E.p, oe + j, ej);
-              fpart = mw::fma(ej, mat_ld<NL>(A, d, i, j), fpart);
+                sum = mw::add(sum, sm[t + gg].v);
+              mw::store<NL>(E.p, oe + j, mw::mul(sum, hinv));
             }
           __syncthreads();
         }
-      const Mw<NL> f = tri_reduce_sum<NL, T>(fpart, sm);
+      // f = sum_j e_j a_ij, the terms dealt to the first TRI_V lanes like those of h0
+      Acc<NL> fp = mw::acc_zero<NL>();
+      if(t < TRI_V)
+        for(int j = t; j < w; j += TRI_V)
+          mw::acc_fma(fp, mw::load<NL>(E.p, oe + j), mat_ld<NL>(A, d, i, j));
+      const Mw<NL> f = tri_reduce_sum<NL>(mw::acc_result(fp), sm);
       const Mw<NL> hh = mw::mul_2exp(mw::mul(f, hinv), -1);
       for(int j = t; j < w; j += T)
         mw::store<NL>(E.p, oe + j, mw::sub(mw::load<NL>(E.p, oe + j), mw::mul(hh, mat_ld<NL>(A, d, i, j))));

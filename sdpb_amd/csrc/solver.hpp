@@ -189,6 +189,8 @@ public:
   virtual const char *comm_name() const = 0;
   virtual void set_profiling(bool on) = 0;
   virtual void set_max_runtime(double seconds) = 0;
+  virtual void set_max_shared_memory(unsigned long long bytes) = 0;
+  virtual std::string memory_plan_json() = 0;
   virtual void request_stop() = 0;
   virtual long host_syncs() const = 0;
   virtual void progress(unsigned long long out[8]) const = 0;
@@ -360,6 +362,9 @@ template <int NL> class Solver : public SolverBase
   // round-3 kernel (k_qsolve_panel2: 8 + 4 dependent aligned adds per sum) for A/B measurements
   bool qsolve_sum_lanes_ = true;
   bool tridiag_wide_ = true; // SDPB_HIP_TRIDIAG_WIDE=0: TRI_T lanes per matrix whatever the rank owns (A/B)
+  DevBuf<int> tri_ids_;      // PSD matrices by size bucket for k_tridiag: the tri_count_large_ with more than TRI_SMALL_N rows first
+  int tri_count_large_ = 0, tri_lanes_small_ = TRI_T, tri_lanes_large_ = TRI_T;
+  static constexpr int TRI_SMALL_N = 24;
   int seq_fault_rank_ = -1; // SDPB_HIP_TEST_SEQ_FAULT=r: rank r perturbs its hash (test of the mismatch path)
   void note_collective(unsigned kind, size_t bytes, int root)
   {
@@ -558,6 +563,64 @@ public:
   const char *comm_name() const override { return world_ == 1 ? "none" : (comm_ ? comm_->name() : "unset"); }
   void set_profiling(bool on) override { profile_ = on; }
   void set_max_runtime(double seconds) override { max_runtime_s_ = seconds; }
+  // --maxSharedMemory (the reference bounds the shared-memory window of the Q stage with it, run.cxx:79-181,
+  // BigInt_Shared_Memory_Syrk_Context.cxx:149-215): here the partial planes of the syrk; 0 = the default plan
+  void set_max_shared_memory(unsigned long long bytes) override
+  {
+    max_shared_bytes_ = (size_t)bytes;
+    HIP_CHECK(hipStreamSynchronize(stream_main_));
+    plan_syrk_part();
+  }
+  // bytes per array class on this rank + the plan of the syrk's partial planes
+  std::string memory_plan_json() override
+  {
+    auto da = [](std::initializer_list<const DevArray *> l) {
+      size_t b = 0;
+      for(const DevArray *a : l)
+        if(a->base)
+          b += a->bytes();
+      return b;
+    };
+    auto db = [](std::initializer_list<size_t> l) {
+      size_t b = 0;
+      for(size_t x : l)
+        b += x;
+      return b;
+    };
+    const unsigned tiles = cdiv(N_, SYRK_EDGE);
+    const int ntile = q_chase_ ? std::max(chase_ntileA_, chase_ntile_ - chase_ntileA_) : (int)(tiles * (tiles + 1) / 2);
+    const SyrkPlan pl = syrk_plan(ntile, (unsigned)Ptot_, syrk_part_budget_words());
+    const SyrkPlan unbounded = syrk_plan(ntile, (unsigned)Ptot_, 0);
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    std::ostringstream o;
+    o << "{\"rank\": " << rank_ << ", \"limbs\": " << NL << ", \"owned_blocks\": " << Jl_ << ", \"rows\": " << Ptot_ << ", \"N\": " << N_
+      << ", \"bytes\": {"
+      << "\"psd_state_and_scratch\": " << da({&X_, &Y_, &Xc_, &Yc_, &dX_, &dY_, &PR_, &mXY_, &R_, &Z_, &W_, &LiX_, &LiY_})
+      << ", \"bases_and_pairings\": " << da({&bases_, &basesT_, &scaled_, &E_, &Et_, &T_, &YQ_, &AX_, &AY_})
+      << ", \"schur_blocks\": " << da({&S_, &LiS_})
+      << ", \"B\": " << da({&BT_}) << ", \"P\": " << da({&PT_})
+      << ", \"P_fixed_point_image\": " << fx_.n * sizeof(uint32_t)
+      << ", \"Q\": " << da({&Q_, &LiQ_}) + db({acc_.n * sizeof(uint32_t), acc64_.n * sizeof(unsigned long long), qpanel_msg_.n * sizeof(uint32_t)})
+      << ", \"syrk_partial_planes\": " << syrk_part_.n * sizeof(uint32_t)
+      << ", \"vectors_and_small\": "
+      << da({&c_, &x_, &dx_, &dres_, &invdS_, &invdX_, &invdY_, &eigD_, &eigE_, &eigD2_, &eigE2_, &b_, &y_, &dy_, &rp_, &norms_, &invnorms_, &invdQ_,
+             &qtmpv_, &part_, &part2_, &red_, &red2_, &lam_, &lam2_, &ratio_, &scal_, &cmby_})
+           + db({colsum_partial_.n * sizeof(uint32_t), toomU_.n * sizeof(uint32_t), xgather_.n * sizeof(uint32_t)})
+      << "}, \"syrk\": {\"tile_edge\": " << SYRK_EDGE << ", \"tiles\": " << pl.ntile << ", \"chunks\": " << pl.nchunk
+      << ", \"tiles_per_chunk\": " << pl.chunk_tiles << ", \"row_splits\": " << pl.nsplit_first
+      << ", \"rows_per_split\": " << (pl.nsplit_first ? cdiv(Ptot_, pl.nsplit_first) : 0) << ", \"planes_per_split\": " << SYRK_PART_PLANES
+      << ", \"partial_bytes\": " << pl.part_words * sizeof(uint32_t) << ", \"partial_bytes_unbounded\": " << unbounded.part_words * sizeof(uint32_t)
+      << ", \"partial_bytes_full_square_layout\": "
+      << (size_t)unbounded.nsplit_first * SYRK_PART_PLANES * ((size_t)N_ * N_ + N_) * sizeof(uint32_t) * (unbounded.uses_part ? 1 : 0)
+      << ", \"budget_bytes\": " << syrk_part_budget_words() * sizeof(uint32_t) << ", \"budget_source\": \""
+      << (std::getenv("SDPB_HIP_SYRK_PART_BYTES") ? "SDPB_HIP_SYRK_PART_BYTES" : max_shared_bytes_ ? "maxSharedMemory" : "device") << "\"}"
+      << ", \"last_syrk_call\": {\"tiles\": " << last_syrk_plan_.ntile << ", \"chunks\": " << last_syrk_plan_.nchunk
+      << ", \"tiles_per_chunk\": " << last_syrk_plan_.chunk_tiles << ", \"row_splits\": " << last_syrk_plan_.nsplit_first
+      << ", \"partial_bytes\": " << last_syrk_plan_.part_words * sizeof(uint32_t) << "}"
+      << ", \"device\": {\"free_bytes\": " << free_b << ", \"total_bytes\": " << total_b << "}}";
+    return o.str();
+  }
   void request_stop() override { stop_requested_.store(1); } // async-signal-safe: a SIGTERM handler may call it
   long host_syncs() const override { return host_syncs_; }
   // [0] iteration, [1] host synchronisation points passed, [2] collectives enqueued, [3] sequence hash,
@@ -706,15 +769,8 @@ private:
     image_alloc(fx_, fx_stride_);
     acc_stride_ = (size_t)N_ * N_ + N_; // N x N outputs + N column sums (k_fx_colsum)
     acc_.alloc(acc_stride_ * ACCW);
-    {
-      // partial outputs of the row-split syrk (sized once, here, not inside the iteration)
-      const unsigned tiles = cdiv(N_, SYRK_EDGE);
-      const int nsplit = syrk_row_splits((int)(tiles * (tiles + 1) / 2) * syrk_group_split(), (unsigned)Ptot_, num_cus_ * syrk_waves_per_simd<FX>(), SYRK_RB, SYRK_SPLIT_ROWS);
-      if(nsplit > 1 || SYRK_TOOM4)
-        syrk_part_.alloc((size_t)nsplit * SYRK_PART_PLANES * acc_stride_);
-      if(SYRK_TOOM4)
-        toomU_.alloc((size_t)2 * (2 * (FX / 4) + 2) * N_);
-    }
+    if(SYRK_TOOM4)
+      toomU_.alloc((size_t)2 * (2 * (FX / 4) + 2) * N_);
     colsum_slices_ = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv(Ptot_, 64)));
     colsum_partial_.alloc((size_t)colsum_slices_ * (FX + 8) * N_); // 2 (FX/2 + 2) or 4 (FX/4 + 2) limbs per column and slice
     syrk_tiles_.upload(syrk_tile_order(N_, 0, nullptr, SYRK_EDGE));
@@ -739,6 +795,21 @@ private:
       qsolve_sum_lanes_ = std::atoi(e) != 0;
     if(const char *e = std::getenv("SDPB_HIP_TRIDIAG_WIDE"))
       tridiag_wide_ = std::atoi(e) != 0;
+    {
+      std::vector<int> ids;
+      for(int pass = 0; pass < 2; ++pass)
+        for(int q = 0; q < 2 * Jl_; ++q)
+          if((h_psd_[q].rows > TRI_SMALL_N) == (pass == 0))
+            ids.push_back(q);
+      tri_count_large_ = 0;
+      for(int q = 0; q < 2 * Jl_; ++q)
+        tri_count_large_ += h_psd_[q].rows > TRI_SMALL_N;
+      tri_ids_.upload(ids);
+      if(const char *e = std::getenv("SDPB_HIP_TRI_T_SMALL"))
+        tri_lanes_small_ = std::max(64, std::atoi(e));
+      if(const char *e = std::getenv("SDPB_HIP_TRI_T_LARGE"))
+        tri_lanes_large_ = std::max(64, std::atoi(e));
+    }
     // opt-in (round-3 advisor): the production transport of its panel messages, ncclBroadcast, has not yet
     // run with more than one rank on hardware; the replicated factorisation uses no collective at all
     dist_cholq_ = false;
@@ -771,13 +842,38 @@ private:
             chase_ntile_ = (int)order.size();
             syrk_tiles_.upload(order);
           }
-          const int slots = num_cus_ * syrk_waves_per_simd<FX>();
-          const int ns = std::max(syrk_row_splits(chase_ntileA_ * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB, SYRK_SPLIT_ROWS),
-                                  syrk_row_splits((chase_ntile_ - chase_ntileA_) * syrk_group_split(), (unsigned)Ptot_, slots, SYRK_RB, SYRK_SPLIT_ROWS));
-          if((ns > 1 || SYRK_TOOM4) && syrk_part_.n < (size_t)ns * SYRK_PART_PLANES * acc_stride_)
-            syrk_part_.alloc((size_t)ns * SYRK_PART_PLANES * acc_stride_);
         }
     }
+    {
+      // The partial planes of the syrk are planned last, against what is left of the device: everything else of this
+      // solver is allocated by now.  Reserve for what comes later (the exchange's buffers and RCCL's, operator scratch):
+      // 1/16 of the device + 1 GiB; never more than 1/8 of the device -- chunking costs nothing measurable while a chunk
+      // keeps thousands of workgroups (profiles/r05_syrk_chunks.txt), and ranks that share a GPU (tests) each see the
+      // memory the others have not taken yet.  SDPB_HIP_SYRK_PART_BYTES / sdpb_hip_set_max_shared_memory override.
+      size_t free_b = 0, total_b = 0;
+      HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+      const size_t reserve = total_b / 16 + ((size_t)1 << 30);
+      size_t b = free_b > reserve ? free_b - reserve : 0;
+      b = std::min(b, total_b / 8);
+      syrk_part_default_words_ = std::max<size_t>(b, (size_t)64 << 20) / sizeof(uint32_t);
+      plan_syrk_part();
+    }
+  }
+  // (re)size syrk_part_ for the iteration's syrk_G call(s) under the current budget
+  void plan_syrk_part()
+  {
+    const size_t budget = syrk_part_budget_words();
+    size_t words = 0;
+    if(q_chase_)
+      words = std::max(syrk_plan(chase_ntileA_, (unsigned)Ptot_, budget).part_words,
+                       syrk_plan(chase_ntile_ - chase_ntileA_, (unsigned)Ptot_, budget).part_words);
+    else
+      {
+        const unsigned tiles = cdiv(N_, SYRK_EDGE);
+        words = syrk_plan((int)(tiles * (tiles + 1) / 2), (unsigned)Ptot_, budget).part_words;
+      }
+    if(words && syrk_part_.n != words)
+      syrk_part_.alloc(words);
   }
 
   void set_default_params()
@@ -1317,10 +1413,13 @@ private:
       }
   }
   // X := X L^{-T} (rows of X are the right-hand sides)
-  void trsm_rlt(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n, unsigned long long *cyc = nullptr)
+  // src: an array with X's layout that holds the right-hand sides (nullptr: X itself, the solve in place)
+  void trsm_rlt(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n, unsigned long long *cyc = nullptr,
+                const DevArray *src = nullptr)
   {
+    const mw::CPtr s = src ? src->cptr() : mw::CPtr(X.p.base, X.p.stride);
     for(int p = 0; p < (int)cdiv(max_n, PB); ++p)
-      launch(k_trsm_rlt_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, p, cyc);
+      launch(k_trsm_rlt_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, s, p, cyc);
   }
   // X := X L^{-1}
   void trsm_rln(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n)
@@ -1520,8 +1619,7 @@ private:
     }
     {
       Timer t(this, "initializeSchurComplementSolver.Q.solve");
-      copy(BT_, PT_);
-      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, block_clock(1));
+      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, block_clock(1), &BT_); // reads B, writes P
     }
     // Optional (off, see overlap_syrk_): with one rank the whole Q chain — norms, fixed-point image,
     // syrk, restore, Cholesky(Q) — can run on the side stream while the main stream goes on to the
@@ -1668,8 +1766,78 @@ private:
       }
     return 21; // measured (profiles/r04s_syrk3_variants.txt): C4 101.6 ms against 102.8 with 7, C3 1.23 against 1.55 ms
   }
+  // The plan of one syrk_G call: the tile list is walked in chunks; every chunk is one product launch + its finishing
+  // kernels over tile-packed partial planes (kernels.hpp: syrk_packed_decode) that fit `budget_words` of `part`.
+  // Analogue of the reference's output windows (bigint_syrk_blas.cxx:200-220: Q is computed window by window when the
+  // residues of the whole output do not fit --maxSharedMemory, BigInt_Shared_Memory_Syrk_Context.cxx:149-215).
+  struct SyrkPlan
+  {
+    int ntile = 0, chunk_tiles = 0, nchunk = 0; // tiles of the call, tiles per chunk (a multiple of 8 unless one chunk), chunks
+    int nsplit_first = 1;                       // row splits of the first chunk (all chunks but a shorter last one)
+    size_t part_words = 0;                      // words of `part` the call needs
+    bool uses_part = false;
+  };
+  SyrkPlan last_syrk_plan_;                  // of the latest syrk_G call (sdpb_hip_memory_plan, the bench line)
+  size_t syrk_part_default_words_ = 0;       // budget found by build_layout()
+  size_t max_shared_bytes_ = 0;              // sdpb_hip_set_max_shared_memory (0: not set)
+  // row splits of a launch over `tiles` tiles: the occupancy rule of syrk_row_splits, bounded by the partial planes
+  // that fit `budget_words`, and no split without rows
+  int syrk_splits_for(int tiles, unsigned nrows, size_t budget_words) const
+  {
+    const int slots = num_cus_ * syrk_waves_per_simd<FX>();
+    int nsplit = syrk_row_splits(tiles * syrk_group_split(), nrows, slots, SYRK_RB, SYRK_SPLIT_ROWS);
+    const size_t per_split = (size_t)SYRK_PART_PLANES * tiles * SYRK_EDGE * SYRK_EDGE;
+    if(budget_words && (size_t)nsplit * per_split > budget_words)
+      nsplit = (int)std::max<size_t>(1, budget_words / per_split);
+    while(nsplit > 1 && (size_t)(nsplit - 1) * (cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB) >= nrows)
+      --nsplit; // (forced split counts on small inputs: the last split must own a row -- its planes are summed)
+    return nsplit;
+  }
+  SyrkPlan syrk_plan(int ntile, unsigned nrows, size_t budget_words) const
+  {
+    SyrkPlan pl;
+    pl.ntile = ntile;
+    const size_t tile_words = (size_t)SYRK_PART_PLANES * SYRK_EDGE * SYRK_EDGE; // one split of one tile
+    const int nsplit_all = syrk_splits_for(ntile, nrows, 0);
+    pl.uses_part = nsplit_all > 1 || SYRK_TOOM4;
+    pl.chunk_tiles = ntile;
+    pl.nchunk = ntile ? 1 : 0;
+    pl.nsplit_first = nsplit_all;
+    if(!pl.uses_part || !ntile)
+      return pl;
+    const size_t need = (size_t)nsplit_all * tile_words * ntile;
+    if(budget_words && need > budget_words)
+      {
+        // as few chunks as fit, of equal size: every launch stays far above the chip's resident workgroups
+        const size_t bw = std::max(budget_words, tile_words); // one tile, one split: the smallest chunk
+        int nchunk = (int)cdiv(need, bw);
+        for(;; ++nchunk)
+          {
+            int ct = (int)cdiv(ntile, nchunk);
+            if(ct >= 64)
+              ct = (int)(cdiv(ct, 8) * 8); // whole rounds of the eight XCDs
+            pl.chunk_tiles = std::min(ntile, ct);
+            pl.nsplit_first = syrk_splits_for(pl.chunk_tiles, nrows, bw);
+            if((size_t)pl.nsplit_first * tile_words * pl.chunk_tiles <= bw || pl.chunk_tiles <= 1)
+              break;
+          }
+        pl.nchunk = (int)cdiv(ntile, pl.chunk_tiles);
+      }
+    pl.part_words = (size_t)pl.nsplit_first * tile_words * pl.chunk_tiles;
+    return pl;
+  }
+  // words of partial planes a syrk_G call may use: SDPB_HIP_SYRK_PART_BYTES (tests, shared GPUs), else
+  // sdpb_hip_set_max_shared_memory (--maxSharedMemory), else what build_layout() found free on the device
+  size_t syrk_part_budget_words() const
+  {
+    if(const char *e = std::getenv("SDPB_HIP_SYRK_PART_BYTES"))
+      return (size_t)std::max(1.0, std::atof(e)) / sizeof(uint32_t);
+    if(max_shared_bytes_)
+      return max_shared_bytes_ / sizeof(uint32_t);
+    return syrk_part_default_words_;
+  }
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
-  // that fills the last round of resident workgroups better; `part` grows on demand
+  // that fills the last round of resident workgroups better; `part` grows on demand (never beyond the budget)
   // ntile_sub >= 0: only the `ntile_sub` tiles tiles_dev points at, which cover the columns [col0, col1) of the lower
   // triangle (a chunk of the chased Q'; the list comes from syrk_tile_order(N, split))
   void syrk_G(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tiles_dev,
@@ -1681,47 +1849,53 @@ private:
     const int ntile = ntile_sub >= 0 ? ntile_sub : (int)(tiles * (tiles + 1) / 2);
     if(col1 < 0)
       col1 = N;
-    const size_t idx0 = (size_t)col0 * N, idx1 = (size_t)col1 * N;
-    if(ntile == 0 || idx1 <= idx0)
+    if(ntile == 0 || col1 <= col0)
       return;
-    const int slots = num_cus_ * syrk_waves_per_simd<FX>();
     const int gsplit = syrk_group_split();
-    const int nsplit = syrk_row_splits(ntile * gsplit, nrows, slots, SYRK_RB, SYRK_SPLIT_ROWS);
-    const unsigned rps = cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB;
-    uint32_t *out = acc;
-    if(nsplit > 1 || SYRK_TOOM4)
+    const SyrkPlan pl = syrk_plan(ntile, nrows, syrk_part_budget_words());
+    if(pl.uses_part && part.n < pl.part_words)
+      part.alloc(pl.part_words);
+    last_syrk_plan_ = pl;
+    constexpr size_t TW = (size_t)SYRK_EDGE * SYRK_EDGE;
+    for(int t0 = 0; t0 < ntile; t0 += pl.chunk_tiles)
       {
-        if(part.n < (size_t)nsplit * SYRK_PART_PLANES * acc_stride)
-          part.alloc((size_t)nsplit * SYRK_PART_PLANES * acc_stride);
-        out = part.p;
-      }
-    if constexpr(SYRK_TOOM4)
-      {
-        if constexpr(SYRK_TOOM4K)
-          launch(k_syrk_fx3<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit * gsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out,
-                 acc_stride, tiles_dev, ntile, nsplit, rps, gsplit);
+        const int nt = std::min(pl.chunk_tiles, ntile - t0);
+        const uint32_t *tl = tiles_dev + t0;
+        const int nsplit = nt == pl.chunk_tiles ? pl.nsplit_first : std::min(pl.nsplit_first, syrk_splits_for(nt, nrows, pl.part_words));
+        const unsigned rps = cdiv(cdiv(nrows, nsplit), SYRK_RB) * SYRK_RB;
+        const size_t ps = (size_t)nt * TW, total = ps; // plane stride of the chunk's partial planes = its packed words
+        const bool packed = pl.uses_part;
+        uint32_t *out = packed ? part.p : acc;
+        const size_t os = packed ? ps : acc_stride;
+        if constexpr(SYRK_TOOM4)
+          {
+            if constexpr(SYRK_TOOM4K)
+              launch(k_syrk_fx3<FX, SYRK_RB>, dim3(8 * cdiv((size_t)nt * nsplit * gsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, os,
+                     tl, nt, nsplit, rps, gsplit);
+            else
+              launch(k_syrk_fx2<FX, SYRK_RB, true>, dim3(8 * cdiv((size_t)nt * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, os, tl, nt,
+                     nsplit, rps, (const uint32_t *)zero_piece_.p, 1);
+            int nsum = nsplit;
+            if constexpr(SYRK_TOOM4K)
+              if(nsplit > 1)
+                {
+                  launch(k_syrk3_sum_splits<FX>, dim3(cdiv(total, WG), 21), dim3(WG), stream_, part.p, nsplit, ps, tl, total, N, col0, col1);
+                  nsum = 1;
+                }
+            launch(k_syrk4_finish<FX>, dim3(cdiv(total, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsum, ps, tl, total,
+                   (const uint32_t *)toomU, acc, acc_stride, N, col0, col1);
+            continue;
+          }
+        else if constexpr(SYRK_TWO_LEVEL)
+          launch(k_syrk_fx2<FX, SYRK_RB>, dim3(8 * cdiv((size_t)nt * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, os, tl, nt, nsplit,
+                 rps, (const uint32_t *)zero_piece_.p, (int)packed);
         else
-        launch(k_syrk_fx2<FX, SYRK_RB, true>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out,
-               acc_stride, tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
-        int nsum = nsplit;
-        if constexpr(SYRK_TOOM4K)
-          if(nsplit > 1)
-            {
-              launch(k_syrk3_sum_splits<FX>, dim3(cdiv(idx1 - idx0, WG), 21), dim3(WG), stream_, part.p, nsplit, acc_stride, N, idx0, idx1);
-              nsum = 1;
-            }
-        launch(k_syrk4_finish<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsum, (const uint32_t *)toomU, acc,
-               acc_stride, N, idx0, idx1);
-        return;
+          launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv((size_t)nt * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, os, tl, nt, nsplit,
+                 rps, (int)packed);
+        if(packed)
+          launch(k_syrk_reduce<FX>, dim3(cdiv(total, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, ps, tl, total, acc, acc_stride, N,
+                 col0, col1);
       }
-    else if constexpr(SYRK_TWO_LEVEL)
-      launch(k_syrk_fx2<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
-             tiles_dev, ntile, nsplit, rps, (const uint32_t *)zero_piece_.p);
-    else
-      launch(k_syrk_fx<FX, SYRK_RB>, dim3(8 * cdiv((size_t)ntile * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, acc_stride,
-             tiles_dev, ntile, nsplit, rps);
-    if(nsplit > 1)
-      launch(k_syrk_reduce<FX>, dim3(cdiv(idx1 - idx0, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsplit, acc, acc_stride, N, idx0, idx1);
   }
   // S_n = sum_r a'_rn behind the N x N block of acc (kernels.hpp: k_fx_colsum)
   void syrk_column_sums(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, uint32_t *partial,
@@ -2058,14 +2232,27 @@ private:
     trsm_rlt(psd(Lc), psd(Li), psd(W), max_n_, max_n_);
     launch(k_transpose<NL>, dim3(cdiv((size_t)max_n_ * max_n_, WG), 2 * Jl_), dim3(WG), stream_, psd(W));
     trsm_rlt(psd(Lc), psd(Li), psd(W), max_n_, max_n_);
-    // lanes per matrix by how many matrices this rank owns (kernels.hpp, k_tridiag): all of them resident -> wider teams
+    // lanes per matrix (kernels.hpp, k_tridiag; the result has the same bits for every choice): per size bucket -- the
+    // rank-2 update of a Householder step has w (w + 1) / 2 entries, 190 at n = 20 and 780 at n = 40 -- and wider where
+    // the rank owns so few matrices that all of them are resident anyway (the launch then lasts as long as the
+    // Householder chain of the largest one: a rank of an 8-GPU job)
     const int mats = 2 * Jl_, slots = num_cus_ * (2048 / 4 / TRI_T); // workgroups of TRI_T lanes resident at 2 waves / SIMD
-    if(TRI_T * 4 <= 1024 && mats * 4 <= slots && tridiag_wide_)
-      launch(k_tridiag<NL, TRI_T * 4>, dim3(mats), dim3(TRI_T * 4), stream_, psd(W), vecn(D), vecn(E));
-    else if(TRI_T * 2 <= 1024 && mats * 2 <= slots && tridiag_wide_)
-      launch(k_tridiag<NL, TRI_T * 2>, dim3(mats), dim3(TRI_T * 2), stream_, psd(W), vecn(D), vecn(E));
-    else
-      launch(k_tridiag<NL, TRI_T>, dim3(mats), dim3(TRI_T), stream_, psd(W), vecn(D), vecn(E));
+    const int widen = !tridiag_wide_ ? 1 : (mats * 4 <= slots ? 4 : (mats * 2 <= slots ? 2 : 1));
+    auto tridiag = [&](int lanes, const int *ids, int count) {
+      if(!count)
+        return;
+      lanes = std::min(512, lanes * widen);
+      if(lanes >= 512)
+        launch(k_tridiag<NL, 512>, dim3(count), dim3(512), stream_, psd(W), vecn(D), vecn(E), ids);
+      else if(lanes >= 256)
+        launch(k_tridiag<NL, 256>, dim3(count), dim3(256), stream_, psd(W), vecn(D), vecn(E), ids);
+      else if(lanes >= 128)
+        launch(k_tridiag<NL, 128>, dim3(count), dim3(128), stream_, psd(W), vecn(D), vecn(E), ids);
+      else
+        launch(k_tridiag<NL, 64>, dim3(count), dim3(64), stream_, psd(W), vecn(D), vecn(E), ids);
+    };
+    tridiag(tri_lanes_large_, (const int *)tri_ids_.p, tri_count_large_); // the long chains first
+    tridiag(tri_lanes_small_, (const int *)tri_ids_.p + tri_count_large_, mats - tri_count_large_);
     launch(k_tridiag_min<NL>, dim3(cdiv(2 * Jl_, EIG_T)), dim3(EIG_T), stream_, vecn(D), vecn(E), F.p, F.p + psd_rows_local_ + 1, lam.ptr());
   }
   // The primal and the dual step length are two independent latency-bound chains (Householder
@@ -2561,9 +2748,8 @@ public:
         float total = 0;
         for(int r = 0; r < std::max(reps, 1); ++r)
           {
-            copy(BT_, PT_);
             HIP_CHECK(hipEventRecord(e0, stream_));
-            trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_);
+            trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, nullptr, &BT_);
             HIP_CHECK(hipEventRecord(e1, stream_));
             HIP_CHECK(hipEventSynchronize(e1));
             float ms = 0;

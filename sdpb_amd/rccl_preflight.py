@@ -82,9 +82,29 @@ def run(rank: int, world: int, device: int, exchange_id, timeout: float = 120.0,
     try:
         if rank == 0:
             child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            while time.time() < deadline:      # the first line is the id (or a failure)
-                line = child.stdout.readline()
-                if not line:
+            # The first line is the id (or a failure).  readline() has no timeout, so a reader thread feeds a queue
+            # and THIS thread waits with one (round-4 advisor: a child stalled before "ID ..." -- torch import, HIP
+            # initialisation, ncclGetUniqueId -- would otherwise block rank 0 here and every other rank in exchange_id).
+            import queue
+            import threading
+            q: "queue.Queue[str | None]" = queue.Queue()
+
+            def _reader(pipe=child.stdout):
+                for ln in iter(pipe.readline, ""):
+                    q.put(ln)
+                    if ln.startswith("ID "):
+                        return          # the rest of the output is collected by communicate() below
+                q.put(None)
+
+            threading.Thread(target=_reader, daemon=True).start()
+            while True:
+                try:
+                    line = q.get(timeout=max(0.05, deadline - time.time()))
+                except queue.Empty:
+                    lines.append(f"no id within {timeout:.0f} s")
+                    child.kill()
+                    break
+                if line is None:
                     break
                 lines.append(line.strip())
                 if line.startswith("ID "):

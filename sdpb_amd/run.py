@@ -32,7 +32,15 @@ def _options(argv: Optional[List[str]] = None):
     ap = argparse.ArgumentParser(prog="sdpb_amd.run", description=__doc__.split("\n\n")[0])
     ap.add_argument("-s", "--sdpDir", required=True)
     ap.add_argument("-o", "--outDir", default=None, help="default: <sdpDir>_out")
-    ap.add_argument("--precision", type=int, default=400)
+    ap.add_argument("--precision", type=int, default=400,
+                    help="bits of the mantissa, rounded up to the next compiled width (128, 256, 448, 512, 704, 768, 1024, 1280, 1536: "
+                         "GMP rounds up to whole limbs too, Solver_Parameters.cxx:26); above 1536 the library refuses with a message "
+                         "naming this range (the reference accepts any precision).  The exact integer Q' is formed from a fixed-point "
+                         "image of at least precision - 32 bits (sdpb_hip_fx_frac_bits); pass precision + 64 for at least `precision`")
+    ap.add_argument("--maxSharedMemory", default="0",
+                    help="bound on the scratch of the Q stage like sdpb's option (bytes, or with a suffix K/M/G as sdpb accepts, e.g. "
+                         "100.1K): here the partial planes of the exact integer syrk; Q' is then computed in chunks of output tiles "
+                         "that fit, with identical results (default 0: what is free on the device, at most 1/8 of it)")
     ap.add_argument("--maxIterations", type=int, default=500)
     ap.add_argument("--maxRuntime", type=float, default=float("inf"))
     for name, default in (("dualityGapThreshold", "1e-30"), ("primalErrorThreshold", "1e-30"),
@@ -53,6 +61,17 @@ def _options(argv: Optional[List[str]] = None):
     ap.add_argument("--noFinalCheckpoint", action="store_true", help="accepted for compatibility")
     ap.add_argument("--lib", default=None, help="path of the C-ABI library (tests: the CPU emulation build)")
     return ap.parse_args(argv)
+
+
+def parse_memory_size(text: str) -> int:
+    """--maxSharedMemory as sdpb writes it: a number of bytes with an optional K / M / G suffix or B, e.g. 100.1K
+    (Solver_Parameters.cxx:61-72: optional suffixes B, K or KB, M or MB, G or GB; test/src/end-to-end.test.cxx:348-357)."""
+    t = str(text).strip().upper().rstrip("B")
+    mult = 1
+    if t and t[-1] in "KMGT":
+        mult = 1024 ** ("KMGT".index(t[-1]) + 1)
+        t = t[:-1]
+    return int(float(t or 0) * mult)
 
 
 def parse_option_like_sdpb(text: str) -> str:
@@ -174,6 +193,15 @@ def solve(argv: Optional[List[str]] = None) -> str:
         previous_handler = signal.signal(signal.SIGTERM, lambda *_: solver.request_stop())
     except ValueError:  # not the main thread (tests): the caller may still use solver.request_stop()
         pass
+    shared = parse_memory_size(o.maxSharedMemory)
+    if shared:
+        solver.set_max_shared_memory(shared)
+    if o.verbosity >= 2:
+        # the reference prints its memory estimates at this verbosity (run.cxx:79-181)
+        plan = solver.memory_plan()
+        print("Memory plan of this rank (bytes): " + ", ".join(f"{k} {v}" for k, v in plan["bytes"].items())
+              + f"; total {sum(plan['bytes'].values())} of {plan['device']['total_bytes']} on the device")
+        print("Q' = P'^T P': " + ", ".join(f"{k} {v}" for k, v in plan["syrk"].items()))
     if o.verbosity >= 1:
         print(f"Initialize SDP solver\n\tprimal dimension: {sdp.P_total}\n\tdual dimension: {sdp.N}"
               f"\n\tSDP blocks: {sdp.J}")

@@ -118,6 +118,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.sdpb_hip_comm_name.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_comm_name.restype = ctypes.c_char_p
     L.sdpb_hip_set_max_runtime.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    if hasattr(L, "sdpb_hip_memory_plan"):   # (absent only from an older build passed as lib_path for A/B timing)
+        L.sdpb_hip_set_max_shared_memory.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
+        L.sdpb_hip_memory_plan.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, size_p]
     L.sdpb_hip_request_stop.argtypes = [ctypes.c_void_p]
     L.sdpb_hip_request_stop.restype = None
     L.sdpb_hip_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -368,6 +371,14 @@ class SDPSolver:
 
     def timers(self) -> dict:
         return json.loads(self._string(self.L.sdpb_hip_timers))
+
+    def set_max_shared_memory(self, nbytes: int):
+        """--maxSharedMemory: bound on the scratch of the Q stage (here the syrk's partial planes); 0 = default plan."""
+        self._chk(self.L.sdpb_hip_set_max_shared_memory(self.h, int(nbytes)))
+
+    def memory_plan(self) -> dict:
+        """Bytes per array class on this rank, the syrk's chunk plan, free/total device memory (run.cxx:79-181)."""
+        return json.loads(self._string(self.L.sdpb_hip_memory_plan))
 
     def run(self, max_runtime: float = float("inf"), on_iteration: Optional[Callable] = None) -> str:
         """SDP_Solver::run: iterate until a terminate reason is set; returns it.  max_runtime is

@@ -51,3 +51,100 @@ def algorithmic_bytes_per_iteration(dims, num_points, N, bytes_per_number: int) 
         t += P * N
     t += N * (N + 1) / 2 + N * N
     return t * bytes_per_number
+
+
+# ---- planned HBM footprint of a rank (round 5) ------------------------------------------------------------------
+# The arrays Solver::build_layout (csrc/solver.hpp) allocates, from the shapes alone, so that a launcher can refuse a
+# plan that cannot fit BEFORE anything is uploaded (the reference estimates its memory per node the same way before it
+# allocates: run.cxx:79-181).  tests/test_gpu_parity_at_size.py compares it with sdpb_hip_memory_plan on the device.
+COMPILED_LIMBS = (6, 10, 16, 18, 24, 26, 34, 42, 50)
+HBM_BYTES = 288 * 10 ** 9
+
+
+def limbs_for(precision: int) -> int:
+    want = 2 * ((precision + 127) // 64)
+    for nl in COMPILED_LIMBS:
+        if nl >= want:
+            return nl
+    raise ValueError(f"--precision {precision} is beyond the compiled widths")
+
+
+def _fx(nl: int):
+    """(FX, image pieces in words per element, tile edge, planes one row split writes, staged rows, waves per SIMD)"""
+    fx = nl - 2
+    if fx >= 14 and fx % 4:
+        fx += 4 - fx % 4
+    toom4 = fx >= 16 and fx % 4 == 0
+    toom4k = fx in (16, 24, 32)
+    two = fx % 4 == 0
+    words = 21 * (fx // 8) if toom4k else 7 * (fx // 4) if toom4 else 9 * (fx // 4) if two else 3 * (fx // 2)
+    planes = 21 * (2 * (fx // 8) + 1) if toom4k else 7 * (2 * (fx // 4) + 1) if toom4 else 2 * fx + 2
+    rb = (16 if fx >= 32 else 32) if two else (16 if fx <= 24 else 8)
+    waves = 3 if toom4k else (3 if fx <= 16 else 2)
+    return fx, words, 32 if toom4k else 16, planes, rb, waves, toom4, toom4k
+
+
+def syrk_row_splits(ntile: int, nrows: int, slots: int, rb: int, max_rows: int) -> int:
+    """kernels.hpp: syrk_row_splits"""
+    import math
+    smin = 1
+    while max_rows and smin < 32 and nrows // smin > max_rows and nrows // (smin + 1) >= 64 * rb:
+        smin += 1
+    best, best_eff = smin, 0.0
+    for s in range(smin, 33):
+        if s > smin and nrows // s < 64 * rb:
+            break
+        items = ntile * s
+        eff = items / (math.ceil(items / slots) * slots)
+        if eff > best_eff + 0.02:
+            best, best_eff = s, eff
+    return best
+
+
+def planned_footprint(dims, num_points, N, precision, owners=None, rank=0, world=1, num_cus=256, hbm_bytes=HBM_BYTES,
+                      max_shared_bytes=0, dist_cholq=False) -> Dict[str, float]:
+    """Bytes per array class this rank will allocate (same classes as sdpb_hip_memory_plan) and their sum."""
+    nl = limbs_for(precision)
+    W = 4 * (nl + 1)
+    fx, words, edge, planes, rb, waves, toom4, toom4k = _fx(nl)
+    psd = bases = scaled = E = pair = schur = bt = vecn = rows = jl = 0
+    for j, (m, K, P, ns, q) in enumerate(shapes(dims, num_points)):
+        if owners is not None and owners[j] != rank:
+            continue
+        jl += 1
+        d = K - 1
+        pr = m * (m + 1) // 2
+        for n, r in zip(ns, (d // 2 + 1, (d + 1) // 2)):
+            psd += n * n
+            vecn += n
+            bases += r * K
+            scaled += K * pr * r
+            E += n * q
+            pair += q * q
+        schur += P * P
+        bt += N * P
+        rows += P
+    out = {"psd_state_and_scratch": 13 * max(psd, 1) * W, "bases_and_pairings": (2 * max(bases, 1) + max(scaled, 1) + 4 * max(E, 1) + 2 * max(pair, 1)) * W,
+           "schur_blocks": 2 * max(schur, 1) * W, "B": max(bt, 1) * W, "P": max(bt, 1) * W}
+    stride = (-(-rows // rb) * rb * N + 64) if toom4k else rows * N
+    out["P_fixed_point_image"] = (max(stride, 1) * words + 4) * 4
+    accw = 2 * fx + 2
+    q_bytes = 2 * N * N * W + (N * N + N) * accw * 4
+    if world > 1:
+        q_bytes += (N * (N + 1) // 2 + N) * accw * 8
+        if dist_cholq:
+            pb = 16 if nl > 34 else 32
+            q_bytes += ((N * pb + pb * pb + pb) * (nl + 1) + 2) * 4
+    out["Q"] = q_bytes
+    tiles = -(-N // edge)
+    ntile = tiles * (tiles + 1) // 2
+    nsplit = syrk_row_splits(ntile * (21 if toom4k else 1), rows, num_cus * waves, rb, 2560 if toom4k else 0) if rows else 1
+    unbounded = nsplit * planes * ntile * edge * edge * 4 if (nsplit > 1 or toom4) else 0
+    budget = max_shared_bytes or hbm_bytes // 8
+    out["syrk_partial_planes"] = min(unbounded, max(budget, planes * edge * edge * 4))
+    out["vectors_and_small"] = (5 * max(rows, 1) + 6 * max(vecn, 1) + 8 * N + 2 * max(jl, 1) * N) * W
+    out["total"] = float(sum(out.values()))
+    out["rows"] = rows
+    out["owned_blocks"] = jl
+    out["syrk_partial_planes_unbounded"] = unbounded
+    return out

@@ -97,6 +97,12 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
   p->totalGlobalMem = (size_t)16 << 30;
   return hipSuccess;
 }
+inline hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes)
+{
+  *free_bytes = (size_t)8 << 30;
+  *total_bytes = (size_t)16 << 30;
+  return hipSuccess;
+}
 template <class T> inline hipError_t hipMalloc(T **p, size_t n)
 {
   *p = (T *)std::malloc(n ? n : 1);

@@ -60,7 +60,40 @@ def main():
             json.dump(out, f, indent=1)
         os.replace(tmp, os.path.join(dest, f"{name}.json"))
 
-    for it in range(iters):
+    # A run of hours survives being stopped: after every iteration the state (x, X, y, Y as the oracle's own mpf records,
+    # orc_get_records / orc_set_records: every bit) goes to <dest>/.<name>.state.pkl, and a later call with the same
+    # arguments continues from it -- the iterate is a function of that state alone, so the continued run is the run that
+    # was stopped (checked on C3 x0.05: identical fixtures).  `resumed_after` in the fixture says where it was picked up.
+    import pickle
+    dest0 = os.environ.get("SDPB_FIXTURE_DIR", HERE)
+    state_path = os.path.join(dest0, f".{name}.state.pkl")
+    start = 0
+    if os.path.exists(state_path) and os.path.exists(os.path.join(dest0, f"{name}.json")) and os.environ.get("SDPB_FIXTURE_RESUME", "1") == "1":
+        with open(os.path.join(dest0, f"{name}.json")) as f:
+            prev = json.load(f)
+        with open(state_path, "rb") as f:
+            st = pickle.load(f)
+        if st["iteration"] == len(prev["iterations"]) and prev["config"] == cfg and prev["scale"] == scale:
+            recs, secs, start = prev["iterations"], prev["oracle_seconds_per_iteration"], st["iteration"]
+            final["resumed_after"] = prev.get("resumed_after", []) + [start]
+            o.set_records("y", st["y"])
+            for j in range(sdp.J):
+                o.set_records("x", st["x"][j], j)
+                for b in (0, 1):
+                    o.set_records("X", st["X"][j][b], j, b)
+                    o.set_records("Y", st["Y"][j][b], j, b)
+            print(f"resumed after iteration {start}", flush=True)
+
+    def save_state(done):
+        L64 = c["precision"] // 64 + 4
+        st = {"iteration": done, "y": o.records("y", limbs64=L64), "x": [o.records("x", j, limbs64=L64) for j in range(sdp.J)],
+              "X": [[o.records("X", j, b, limbs64=L64) for b in (0, 1)] for j in range(sdp.J)],
+              "Y": [[o.records("Y", j, b, limbs64=L64) for b in (0, 1)] for j in range(sdp.J)]}
+        with open(state_path + ".tmp", "wb") as f:
+            pickle.dump(st, f, protocol=4)
+        os.replace(state_path + ".tmp", state_path)
+
+    for it in range(start, iters):
         t = time.time()
         if o.iterate():
             assert to_term, o.terminate_reason
@@ -75,6 +108,8 @@ def main():
         recs.append(rec)
         print(f"iteration {it + 1}: {secs[-1]:.0f}s  P-obj={rec['P-obj'][:30]}", flush=True)
         write()
+        if to_term:
+            save_state(it + 1)
     print("wrote", name)
 
 

@@ -26,15 +26,22 @@ def test_emulated_library_matches_reference_golden(name, limit):
     s.close()
 
 
-@pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (128, 70, 21, "3"), (512, 45, 18, None),
-                                                        (512, 100, 18, "3"), (512, 40, 47, None), (512, 70, 81, "2"), (512, 33, 34, None),
-                                                        (768, 33, 17, None), (768, 37, 45, "2"), (664, 20, 17, None),
-                                                        (1024, 40, 18, None), (1024, 40, 18, "2"), (1024, 35, 49, None), (1280, 36, 17, None),
-                                                        (1280, 70, 17, "2")])
-def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
+_INT_SYRK = [(128, 37, 21, None), (128, 70, 21, "3"), (512, 45, 18, None), (512, 100, 18, "3"), (512, 40, 47, None), (512, 70, 81, "2"),
+             (512, 33, 34, None), (768, 33, 17, None), (768, 37, 45, "2"), (664, 20, 17, None), (1024, 40, 18, None), (1024, 40, 18, "2"),
+             (1024, 35, 49, None), (1280, 36, 17, None), (1280, 70, 17, "2")]
+# a memory budget (bytes) below the partial planes of the whole output: Q' in chunks of output tiles (Solver::syrk_plan; 32 x 32
+# tiles at 512 ... 1024 bits, 16 x 16 else) -- the analogue of the reference's output windows (bigint_syrk_blas.cxx:200-220)
+_INT_SYRK_CHUNKED = [(512, 70, 81, "2", 1.0e6), (512, 100, 97, None, 5.0e5), (128, 70, 41, "3", 2.5e4), (1024, 40, 49, "2", 1.6e6),
+                     (1280, 70, 33, "2", 7.0e5), (768, 37, 45, "2", 1.3e6)]
+
+
+@pytest.mark.parametrize("precision,rows,cols,splits,budget", [c + (None,) for c in _INT_SYRK] + _INT_SYRK_CHUNKED)
+def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, budget, monkeypatch):
     import random
     if splits:
         monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", splits)  # row-split partial sums + k_syrk_reduce
+    if budget:
+        monkeypatch.setenv("SDPB_HIP_SYRK_PART_BYTES", str(int(budget)))
     from oracle.oracle import Oracle
     sdp, meta, _, _ = parity.load_case("1d")
     s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
@@ -61,6 +68,9 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, monkeypatch):
         vals[16 + 2 * k] = 2 ** bit - 2 ** fb - 1 if bit < fb else -(2 ** (bit - 1))
     got = s.op_int_syrk(rows, cols, vals)
     want = o.int_syrk(rows, cols, vals)  # upper triangle, column-major
+    if budget:
+        call = s.memory_plan()["last_syrk_call"]
+        assert call["chunks"] > 1 and call["partial_bytes"] <= budget, call
     for j in range(cols):
         for i in range(cols):
             if i >= j:
@@ -229,3 +239,52 @@ def test_emulated_five_panels_of_Q():
         assert parity.maxrel(s.array("dy"), o.array("dy")) <= -256
     s.close()
     o.close()
+
+
+def test_emulated_memory_plan_and_max_shared_memory():
+    """sdpb_hip_memory_plan / sdpb_hip_set_max_shared_memory (--maxSharedMemory; run.cxx:79-181,
+    BigInt_Shared_Memory_Syrk_Context.cxx:149-215): with a bound below the partial planes of the whole Q' the iteration computes
+    Q' in chunks of output tiles and every field of every iteration keeps its bits."""
+    from sdpb_amd.synthetic import make_sdp
+    sdp = make_sdp([1] * 6, [30] * 6, 150, 512, seed=13)   # N = 150: 5 x 6 / 2 = 15 tiles of 32 x 32
+    a = SDPSolver(sdp, 512, parity.DEFAULT_PARAMS, lib_path=libs.emu_lib())
+    plan = a.memory_plan()
+    assert plan["syrk"]["chunks"] == 1 and plan["syrk"]["tiles"] == 15 and plan["syrk"]["budget_source"] == "device"
+    assert plan["bytes"]["syrk_partial_planes"] >= plan["syrk"]["partial_bytes"] > 0
+    # tile-packed planes: the lower triangle only, about half of the N x N planes of rounds 1-4
+    assert plan["syrk"]["partial_bytes_unbounded"] < 0.75 * plan["syrk"]["partial_bytes_full_square_layout"]
+    assert sum(plan["bytes"].values()) > 0 and plan["bytes"]["B"] == plan["bytes"]["P"] > 0
+    b = SDPSolver(sdp, 512, parity.DEFAULT_PARAMS, lib_path=libs.emu_lib())
+    bound = plan["syrk"]["partial_bytes"] // 4
+    b.set_max_shared_memory(bound)
+    pb = b.memory_plan()
+    assert pb["syrk"]["budget_source"] == "maxSharedMemory" and pb["syrk"]["chunks"] >= 4, pb["syrk"]
+    assert pb["syrk"]["partial_bytes"] <= bound and pb["bytes"]["syrk_partial_planes"] <= bound
+    for it in range(2):
+        assert not a.iterate() and not b.iterate()
+        assert a.scalars() == b.scalars(), it + 1
+    assert b.memory_plan()["last_syrk_call"]["chunks"] == pb["syrk"]["chunks"]
+    b.set_max_shared_memory(0)   # back to the default plan
+    assert b.memory_plan()["syrk"]["chunks"] == 1
+    assert not a.iterate() and not b.iterate()
+    assert a.scalars() == b.scalars()
+    a.close()
+    b.close()
+
+
+# widest --precision each compiled limb count serves (limbs = 2 floor((p + 127) / 64), GMP's allocation)
+TOP_PRECISION = {6: 128, 10: 256, 16: 448, 18: 512, 24: 704, 26: 768, 34: 1024, 42: 1280, 50: 1536}
+
+
+@pytest.mark.parametrize("limbs", [6, 18, 24, 26, 34, 42])
+def test_emulated_Q_image_keeps_at_least_precision_minus_32_bits(limbs):
+    """The floor under the fixed-point image of P' (round-4 review: 505 -> 495 -> 487 fraction bits at --precision 512, each
+    multiplication level paid partly in guard bits; the reference truncates at 2^precision, Matrix_Normalizer.cxx:174-192,
+    compute_Q.cxx:107).  A further level that takes the image below precision - 32 bits must fail here, not pass silently
+    behind thresholds calibrated on the device's own error."""
+    p = TOP_PRECISION[limbs]
+    sdp, _, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, p, lib_path=libs.emu_lib())
+    assert s.limbs == limbs
+    assert s.fx_frac_bits >= p - 32, (p, s.fx_frac_bits)
+    s.close()

@@ -122,6 +122,52 @@ def test_int_syrk_bit_exact(precision, rows, cols, splits, monkeypatch):
     s.close()
 
 
+@pytest.mark.parametrize("precision,rows,cols,splits,budget", [(512, 700, 200, "4", 4.0e6), (512, 333, 113, None, 1.5e6), (256, 300, 90, "4", 2.0e5),
+                                                               (1024, 150, 81, "3", 3.0e6), (1280, 200, 50, "2", 1.0e6), (768, 120, 81, "2", 2.0e6)])
+def test_int_syrk_in_chunks_under_a_memory_budget_is_bit_exact(precision, rows, cols, splits, budget, monkeypatch):
+    """The analogue of the reference's output windows (bigint_syrk_blas.cxx:200-220, BigInt_Shared_Memory_Syrk_Context.cxx:149-215,
+    --maxSharedMemory): a budget far below the partial planes of the whole Q' (row splits x limb planes x tile-packed lower
+    triangle) makes Solver::syrk_G walk the output tiles in chunks through ONE bounded buffer; every entry stays bit-exact
+    against GMP."""
+    from oracle.oracle import Oracle
+    if splits:
+        monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", splits)
+    monkeypatch.setenv("SDPB_HIP_SYRK_PART_BYTES", str(int(budget)))
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    o = Oracle(sdp, precision)
+    fxbits = s.fx_frac_bits
+    rng = random.Random(rows + cols)
+    vals = [rng.randrange(-(2 ** fxbits) + 1, 2 ** fxbits) for _ in range(rows * cols)]
+    vals[0], vals[1], vals[-1] = 0, -(2 ** fxbits) + 1, 2 ** fxbits - 1
+    got = s.op_int_syrk(rows, cols, vals)
+    want = o.int_syrk(rows, cols, vals)
+    call = s.memory_plan()["last_syrk_call"]
+    assert call["chunks"] >= 3 and call["partial_bytes"] <= budget, call
+    for j in range(cols):
+        for i in range(j, cols):
+            assert got[i + j * cols] == want[j + i * cols], (i, j)
+    s.close()
+
+
+@pytest.mark.parametrize("limbs,precision", [(6, 128), (10, 256), (16, 448), (18, 512), (24, 704), (26, 768), (34, 1024), (42, 1280), (50, 1536)])
+def test_Q_image_keeps_at_least_precision_minus_32_bits(limbs, precision):
+    """The floor under the fixed-point image of P' the exact integer Q' = P'^T P' is formed from, at the widest --precision
+    every compiled limb count serves (the reference truncates P' at 2^precision: Matrix_Normalizer.cxx:174-192,
+    compute_Q.cxx:107).  Round-4 review: the image went 505 -> 495 -> 487 bits at --precision 512 as multiplication levels
+    were added; one more guard bit below precision - 32 fails here.  A user who needs >= p bits in Q' passes --precision p + 64
+    (INTEGRATION.md section 3)."""
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    assert s.limbs == limbs
+    assert s.fx_frac_bits >= precision - 32, (precision, s.fx_frac_bits)
+    wider = _solver(sdp, precision + 64) if precision + 64 <= 1536 else None
+    if wider is not None:
+        assert wider.fx_frac_bits >= precision, (precision + 64, wider.fx_frac_bits)   # the documented way to a full-width image
+        wider.close()
+    s.close()
+
+
 # ---- whole iterations vs the reference's golden traces (reference tolerance 2^-99)
 GOLDEN = [("1d", None), ("1d-old-sampling", 40), ("1d-duplicate-poles", 40), ("1d-constraints", None),
           ("dfibo", None), ("singlet_cT", None), ("singlet_allowed_primal_jump", None),

@@ -274,3 +274,40 @@ def test_chased_cholesky_Q_gives_the_same_bits(monkeypatch):
         s.close()
     assert traces[0] == traces[1] == traces[2]
 
+
+
+def test_max_shared_memory_bounds_the_syrk_and_keeps_every_bit(monkeypatch):
+    """sdpb_hip_set_max_shared_memory (--maxSharedMemory: run.cxx:79-181, BigInt_Shared_Memory_Syrk_Context.cxx:149-215) and
+    sdpb_hip_memory_plan on C4 x0.25 (N = 250: 36 output tiles of 32 x 32, 10 000 rows in row splits): with a bound of a
+    fifth of the partial planes the iteration computes Q' in >= 5 chunks through one buffer that respects the bound, and
+    whole iterations agree with the unbounded schedule to the last bit -- also with the chased Cholesky(Q), whose two
+    column chunks are then chunked once more."""
+    c = _shape("C4", 0.25)
+    traces, plans = [], []
+    for bound_frac, chase in ((0, "0"), (5, "0"), (5, "1")):
+        monkeypatch.setenv("SDPB_HIP_Q_CHASE", chase)
+        sdp, s, _ = _pair(c, oracle=False)
+        plan = s.memory_plan()
+        if bound_frac:
+            bound = plans[0]["syrk"]["partial_bytes"] // bound_frac
+            s.set_max_shared_memory(bound)
+            plan = s.memory_plan()
+            assert plan["syrk"]["budget_source"] == "maxSharedMemory"
+            assert plan["syrk"]["partial_bytes"] <= bound and plan["bytes"]["syrk_partial_planes"] <= bound, plan["syrk"]
+            assert plan["syrk"]["chunks"] >= (5 if chase == "0" else 3), plan["syrk"]
+        else:
+            assert plan["syrk"]["chunks"] == 1 and plan["syrk"]["tiles"] == 36, plan["syrk"]
+            assert plan["syrk"]["partial_bytes_unbounded"] < 0.6 * plan["syrk"]["partial_bytes_full_square_layout"]
+            total = sum(plan["bytes"].values())
+            assert 0 < total < plan["device"]["total_bytes"] and plan["bytes"]["B"] == plan["bytes"]["P"] > 0
+        plans.append(plan)
+        t = []
+        for _ in range(3):
+            assert not s.iterate()
+            t.append(s.scalars())
+        t.append(s.array("dy")[:64])
+        traces.append(t)
+        if bound_frac:
+            assert s.memory_plan()["last_syrk_call"]["chunks"] >= 2
+        s.close()
+    assert traces[0] == traces[1] == traces[2]

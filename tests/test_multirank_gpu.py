@@ -89,8 +89,10 @@ def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=No
             s.set_collectives(*make_collectives(dev))
         owners = [s.block_owner(j) for j in range(sdp.J)]
         from sdpb_amd.solver import SDPBError
-        recs = []
+        recs, secs = [], []
+        import time as _t
         for _ in range(n_iter):
+            t_it = _t.time()
             try:
                 if s.iterate():
                     recs.append({"terminated": s.terminate_reason})
@@ -99,9 +101,12 @@ def _worker(rank, world, port, case, n_iter, q, gpu=True, env=None, emu_panel=No
                 recs.append({"error": (e.code, str(e))})
                 break
             recs.append(s.scalars())
+            secs.append(round(_t.time() - t_it, 3))
         t = s.timers()
         comm = {k: v for k, v in t.items() if k.startswith("comm.")}
         comm["progress"] = s.progress()
+        comm["memory_plan"] = s.memory_plan()
+        comm["seconds_per_iteration"] = secs
         q.put((rank, owners, recs, comm, s.comm_name))
         s.close()
     finally:
@@ -214,6 +219,36 @@ def test_ranks_sharing_one_gpu_match_the_oracle_at_bench_shape(world):
         bad, worst = parity.compare_iteration(results[0][2][it], o.scalars(), tol_bits=precision // 2)
         assert not bad, (it + 1, bad)
     o.close()
+
+
+@pytest.mark.gpu
+def test_two_C5_slices_over_the_in_library_rccl_exchange():
+    """The largest piece of BASELINE.json's config 5 a test run can afford: C5J2048 = a QUARTER of C5 (J = 2048 blocks of
+    m = 6, the full N = 2048, --precision 1024, P_tot = 86 016), two ranks that each hold exactly what a rank of the 8-GPU
+    job holds (a C5 slice: 58 GB of device arrays) and exchange through the library's own RCCL communicator -- the
+    1.1-GB u64 all-reduce of Q' (restore_and_reduce.cxx:137-212), the result blocks and the N-vectors.  The ranks share
+    the box's one GPU (NCCL_HOSTID, socket transport), so this says nothing about xGMI.  Checked: ranks bit-identical,
+    owners a partition, collective sequences equal, every rank's syrk partial planes inside its memory bound
+    (sdpb_hip_memory_plan), and every field of every iteration within 2^-900 of the SAME SDP solved by one rank (the two
+    decompositions differ in the order of the cross-rank sums only).  profiles/tools/c5_half_multirank.py is the same
+    at twice the size with 4 and 2 ranks."""
+    from sdpb_amd.solver import SDPSolver
+    case, n_iter, bound = "C5J2048", 2, 12 << 30
+    sdp, precision, params, src, _ = _load(case)
+    res = run_ranks(2, case, n_iter, timeout=2400, env={"SDPB_HIP_SYRK_PART_BYTES": str(bound)}, transport="rccl-one-gpu")
+    check_ranks(res, 2, sdp.J, transport="rccl-one-gpu")
+    for rank, owners, recs, comm, name in res:
+        plan = comm["memory_plan"]
+        assert plan["owned_blocks"] == sdp.J // 2 and plan["rows"] == sdp.P_total // 2
+        assert plan["syrk"]["partial_bytes"] <= bound < plan["syrk"]["partial_bytes_unbounded"] and plan["syrk"]["chunks"] >= 2, plan["syrk"]
+        assert plan["bytes"]["syrk_partial_planes"] <= bound
+        assert comm["comm.allreduce_bytes"] / n_iter > 1.0e9     # the lower triangle of Q' + column sums, 66 u64 planes
+    one = SDPSolver(sdp, precision, params, lib_path=libs.product_lib(), block_source=src)
+    for it in range(n_iter):
+        assert not one.iterate()
+        bad, worst = parity.compare_iteration(res[0][2][it], one.scalars(), tol_bits=900)
+        assert not bad, (it + 1, bad)
+    one.close()
 
 
 def _gpus():

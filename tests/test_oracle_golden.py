@@ -79,6 +79,9 @@ def test_reference_crt_blas_algorithm_matches_exact_integers(precision, rows, co
     vals = [rng.randrange(-(2 ** precision) + 1, 2 ** precision) for _ in range(rows * cols)]
     vals[0], vals[1], vals[2] = 2 ** precision - 1, -(2 ** precision) + 1, 0
     got = ref.int_syrk(vals, rows, cols, precision)
+    # the same stage with steps 2 and 4 compiled on GMP (oracle/sdpb_oracle.cpp: orc_refq_residues = mpz_fdiv_ui per prime,
+    # orc_refq_crt = mpz_addmul_ui over the primes + one reduction modulo their product): what bench.py times, CRT included
+    assert ref.int_syrk_gmp(vals, rows, cols, precision) == got
     sdp, _, _, _ = parity.load_case("1d")
     o = Oracle(sdp, precision)
     port = o.int_syrk(rows, cols, vals)          # upper triangle, column-major: entry (i <= j) at i + j * cols
@@ -92,3 +95,14 @@ def test_reference_crt_blas_algorithm_matches_exact_integers(precision, rows, co
     assert primes == sorted(primes, reverse=True) and primes[0] < 1664544 and (primes[0] // 2) ** 2 * rows < 2 ** 53
     # the shape the bench quotes: k = 40 000 rows at --precision 512 -> 53 primes of ~19.9 bits
     assert len(ref.calculate_primes(ref.output_bits(512, 512, 40000), 40000)) == 53
+
+
+def test_reference_algorithm_timer_runs_the_whole_stage():
+    """time_q_stage_gmp (bench.py's `q_stage_reference_algorithm_s`): residues, one dsyrk per prime accumulated over row
+    chunks, and the CRT of every output of the lower triangle -- all three timed, `crt_included`."""
+    from oracle import bigint_syrk_blas as ref
+    r = ref.time_q_stage_gmp(300, 40, 512, 40000, threads=2, chunk_rows=128)
+    assert r["crt_included"] and r["crt_outputs"] == 40 * 41 // 2 and r["primes"] == 53
+    assert r["residues_s"] > 0 and r["dsyrk_s"] > 0 and r["crt_s"] > 0
+    # chunked accumulation (beta = 1) gives the same sums as one call: same checksum of the recombined outputs
+    assert ref.time_q_stage_gmp(300, 40, 512, 40000, threads=1, chunk_rows=300)["checksum"] == r["checksum"]

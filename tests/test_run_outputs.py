@@ -91,6 +91,22 @@ def test_driver_writes_sdpb_result_files_emulated(tmp_path):
     assert n == m == len(rows) and all(len(r) == n for r in rows)
 
 
+def test_max_shared_memory_option_and_memory_plan_of_the_driver(tmp_path, capsys):
+    """--maxSharedMemory as the reference's end-to-end tests pass it (100.1K: end-to-end.test.cxx:348-357; suffixes of
+    Solver_Parameters.cxx:61-72) reaches sdpb_hip_set_max_shared_memory, --verbosity 2 prints the rank's memory plan
+    (the reference prints its estimates there, run.cxx:79-181), and the result files are the reference's."""
+    assert run.parse_memory_size("100.1K") == int(100.1 * 1024) and run.parse_memory_size("2GB") == 2 << 30
+    assert run.parse_memory_size("0") == 0 and run.parse_memory_size("3M") == 3 << 20 and run.parse_memory_size("17B") == 17
+    out_dir = str(tmp_path / "out")
+    argv = _argv("dfibo", out_dir, libs.emu_lib()) + ["--maxSharedMemory", "100.1K"]
+    argv[argv.index("--verbosity") + 1] = "2"
+    assert run.solve(argv)
+    text = capsys.readouterr().out
+    assert "Memory plan of this rank (bytes): psd_state_and_scratch" in text and "budget_source maxSharedMemory" in text
+    assert f"budget_bytes {int(100.1 * 1024) // 4 * 4}" in text
+    _check_outputs("dfibo", out_dir)
+
+
 def test_text_checkpoint_restart_continues_the_same_trajectory(tmp_path):
     _checkpoint_restart(tmp_path, libs.emu_lib())
 
