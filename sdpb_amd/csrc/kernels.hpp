@@ -3546,7 +3546,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 template <int FX, int RBG>
 __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   k_syrk_fx3(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
-             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, int gsplit)
+             const uint32_t *tile_list, int ntile, int nsplit, unsigned rows_per_split, int gsplit, int order)
 {
   // gsplit = 7 (21): a workgroup takes the three products of ONE Toom-4 group (one product) of its (tile, row split)
   // instead of all 21 (the sweeps are independent): more workgroups where the output has few tiles, a shorter tail everywhere
@@ -3558,8 +3558,18 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   static_assert(NPAIR % WG == 0, "a pass stages a whole number of units per lane");
   const uint32_t *fx = (const uint32_t *)__builtin_assume_aligned(fx_in, 4);
   const int nitem = ntile * nsplit * gsplit, per = (nitem + 7) / 8;
-  const int item = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
-  if((int)(blockIdx.x / 8) >= per || item >= nitem)
+  int item = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+  if(order == 1)
+    {
+      // (split, product)-major over the WHOLE chip (an experiment, SDPB_HIP_SYRK_ORDER=1; profiles/r05_syrk_order.txt): every
+      // XCD takes a contiguous eighth of the tiles of the same (split, product), so that all resident workgroups stream
+      // ONE panel set of rows_per_split x N pieces (20 MB on C4) at a time instead of eight of them
+      const int tper = (ntile + 7) / 8, slot = (int)(blockIdx.x / 8), sgx = slot / tper, tl = (int)(blockIdx.x % 8) * tper + slot % tper;
+      if(sgx >= nsplit * gsplit || tl >= ntile)
+        return;
+      item = sgx * ntile + tl;
+    }
+  else if((int)(blockIdx.x / 8) >= per || item >= nitem)
     return;
   // items that follow each other share the rows and the group, i.e. the operand panels of neighbouring tiles
   const int sg = item / ntile, tile = item % ntile, split = sg / gsplit;

@@ -206,19 +206,30 @@ public:
   virtual std::string op_syrk_Q(int rows, int cols, const char *P_colmajor) = 0;
 };
 
-// kernel launches of this process (all solvers): the latency floor of a small SDP is launches x dispatch cost,
-// bench.py reports launches per iteration next to the host synchronisation points
-inline std::atomic<unsigned long long> &launch_counter()
+// kernel launches of the solver whose entry point is running on this thread (round-4 advisor: the figure in timers_json
+// was a process-wide counter): launch() adds to the counter a LaunchScope has installed for the calling thread -- the
+// iteration entry points of a Solver install their own -- and to a thread's stray counter otherwise.  The latency floor
+// of a small SDP is launches x dispatch cost; bench.py reports launches per iteration next to the host synchronisations.
+inline unsigned long long *&launch_sink()
 {
-  static std::atomic<unsigned long long> n{0};
-  return n;
+  static thread_local unsigned long long stray = 0;
+  static thread_local unsigned long long *sink = &stray;
+  return sink;
 }
+struct LaunchScope
+{
+  unsigned long long *prev;
+  explicit LaunchScope(unsigned long long *mine) : prev(launch_sink()) { launch_sink() = mine; }
+  ~LaunchScope() { launch_sink() = prev; }
+  LaunchScope(const LaunchScope &) = delete;
+  LaunchScope &operator=(const LaunchScope &) = delete;
+};
 template <class... KArgs, class... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args &&...args)
 {
   if(grid.x == 0 || grid.y == 0 || grid.z == 0)
     return;
-  launch_counter().fetch_add(1, std::memory_order_relaxed);
+  ++*launch_sink();
   hipLaunchKernelGGL(kernel, grid, block, 0, stream, std::forward<Args>(args)...);
   HIP_CHECK(hipGetLastError());
 }
@@ -362,6 +373,7 @@ template <int NL> class Solver : public SolverBase
   // round-3 kernel (k_qsolve_panel2: 8 + 4 dependent aligned adds per sum) for A/B measurements
   bool qsolve_sum_lanes_ = true;
   bool tridiag_wide_ = true; // SDPB_HIP_TRIDIAG_WIDE=0: TRI_T lanes per matrix whatever the rank owns (A/B)
+  unsigned long long launches_ = 0; // kernels launched by this solver's init_state / iterate / schur_* (LaunchScope)
   DevBuf<int> tri_ids_;      // PSD matrices by size bucket for k_tridiag: the tri_count_large_ with more than TRI_SMALL_N rows first
   int tri_count_large_ = 0, tri_lanes_small_ = TRI_T, tri_lanes_large_ = TRI_T;
   static constexpr int TRI_SMALL_N = 24;
@@ -955,7 +967,7 @@ public:
        << ", \"kernel.k_syrk_fx.limb_macs\": "
        << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TOOM4K ? 21.0 / 64 : SYRK_TOOM4 ? 7.0 / 16 : SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 21 (FX/8)^2, 7 or 9 (FX/4)^2, or 3 (FX/2)^2 per product
        << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TOOM4 ? 0 : SYRK_TWO_LEVEL ? 2 : 1) << ", \"kernel.k_syrk_fx.toom4\": " << (SYRK_TOOM4 ? 1 : 0) << ", \"kernel.k_syrk_fx.toom4k\": " << (SYRK_TOOM4K ? 1 : 0)
-       << ", \"host_syncs\": " << host_syncs_ << ", \"launches\": " << launch_counter().load()
+       << ", \"host_syncs\": " << host_syncs_ << ", \"launches\": " << launches_
        << ", \"iterations\": " << iteration_ << ", \"comm.world\": " << world_ << ", \"comm.ranks\": " << (comm_ ? comm_->ranks() : (world_ == 1 ? 1 : 0))
        << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
        << ", \"comm.allgather_bytes\": " << xc_allgather_bytes_ << ", \"comm.allreduce_calls\": " << xc_allreduce_calls_
@@ -1124,6 +1136,7 @@ public:
   // SDP_Solver.cxx:23-38
   void init_state() override
   {
+    LaunchScope launches_of_this_solver(&launches_);
     for(DevArray *a : {&X_, &Y_, &x_, &y_, &dx_, &dy_, &dX_, &dY_})
       HIP_CHECK(hipMemsetAsync(a->base, 0, a->bytes(), stream_));
     upload_scalar(S_ALPHA_P, initial_matrix_scale_primal_);
@@ -1870,8 +1883,12 @@ private:
         if constexpr(SYRK_TOOM4)
           {
             if constexpr(SYRK_TOOM4K)
-              launch(k_syrk_fx3<FX, SYRK_RB>, dim3(8 * cdiv((size_t)nt * nsplit * gsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, os,
-                     tl, nt, nsplit, rps, gsplit);
+              {
+                static const int order = std::getenv("SDPB_HIP_SYRK_ORDER") ? std::atoi(std::getenv("SDPB_HIP_SYRK_ORDER")) : 0;
+                const size_t blocks = order == 1 ? (size_t)8 * cdiv(nt, 8) * nsplit * gsplit : (size_t)8 * cdiv((size_t)nt * nsplit * gsplit, 8);
+                launch(k_syrk_fx3<FX, SYRK_RB>, dim3((unsigned)blocks), dim3(WG), stream_, fx, fx_stride, nrows, N, out, os, tl, nt, nsplit, rps,
+                       gsplit, order);
+              }
             else
               launch(k_syrk_fx2<FX, SYRK_RB, true>, dim3(8 * cdiv((size_t)nt * nsplit, 8)), dim3(WG), stream_, fx, fx_stride, nrows, N, out, os, tl, nt,
                      nsplit, rps, (const uint32_t *)zero_piece_.p, 1);
@@ -2251,8 +2268,16 @@ private:
       else
         launch(k_tridiag<NL, 64>, dim3(count), dim3(64), stream_, psd(W), vecn(D), vecn(E), ids);
     };
-    tridiag(tri_lanes_large_, (const int *)tri_ids_.p, tri_count_large_); // the long chains first
-    tridiag(tri_lanes_small_, (const int *)tri_ids_.p + tri_count_large_, mats - tri_count_large_);
+    // ONE launch (the matrices with the long chains first in `ids`) unless the buckets are given different widths: two
+    // launches on a stream run one after the other, and the second bucket would idle behind the tail of the first
+    // (measured: + 0.8 ms per iteration on C4, profiles/r05_tridiag_lanes.txt)
+    if(tri_lanes_small_ == tri_lanes_large_)
+      tridiag(tri_lanes_large_, (const int *)tri_ids_.p, mats);
+    else
+      {
+        tridiag(tri_lanes_large_, (const int *)tri_ids_.p, tri_count_large_);
+        tridiag(tri_lanes_small_, (const int *)tri_ids_.p + tri_count_large_, mats - tri_count_large_);
+      }
     launch(k_tridiag_min<NL>, dim3(cdiv(2 * Jl_, EIG_T)), dim3(EIG_T), stream_, vecn(D), vecn(E), F.p, F.p + psd_rows_local_ + 1, lam.ptr());
   }
   // The primal and the dual step length are two independent latency-bound chains (Householder
@@ -2418,6 +2443,7 @@ public:
   // the step lengths; everything else is queued ahead of the GPU.
   bool iterate() override
   {
+    LaunchScope launches_of_this_solver(&launches_);
     if(!started_)
       {
         started_ = true;
@@ -2490,6 +2516,7 @@ public:
   // without touching x, X, y, Y.  Raises the same errors as the iteration.
   void schur_solver_init() override
   {
+    LaunchScope launches_of_this_solver(&launches_);
     launch(k_store_words4<0>, dim3(1), dim3(64), stream_, xwords(), 0xffffffffu, 0u, 0u, 0u);
     factor_X_and_Y();
     compute_bilinear_pairings();
@@ -2502,6 +2529,7 @@ public:
   // and dy (set_array "dy"), out the solution in the same arrays
   void schur_solve() override
   {
+    LaunchScope launches_of_this_solver(&launches_);
     copy(dy_, rp_);
     solve_schur_complement_equation();
     HIP_CHECK(hipStreamSynchronize(stream_));
