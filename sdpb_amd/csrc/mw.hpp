@@ -458,16 +458,26 @@ template <int I0, int I1, int BASE, int W> MW_HD uint32_t nonzero_mask(const uin
 // on the dependent path of every subtraction)
 template <int W> MW_HD int top_nonzero(const uint32_t (&w)[W])
 {
-  static_assert(W <= 64, "two 32-bit masks");
+  static_assert(W <= 128, "four 32-bit masks");
   if constexpr(W <= 32)
     {
       const uint32_t m = nonzero_mask<0, W - 1, 0, W>(w);
       return m ? 31 - (int)clz32(m) : -1;
     }
-  else
+  else if constexpr(W <= 64)
     {
       const uint32_t mh = nonzero_mask<32, W - 1, 32, W>(w), ml = nonzero_mask<0, 31, 0, W>(w);
       return mh ? 63 - (int)clz32(mh) : (ml ? 31 - (int)clz32(ml) : -1);
+    }
+  else
+    {
+      // the widths above 1536 bits (--precision 2048: 66 limbs and their guard limbs)
+      uint32_t m3 = 0;
+      if constexpr(W > 96)
+        m3 = nonzero_mask<96, W - 1, 96, W>(w);
+      const uint32_t m2 = nonzero_mask<64, (W > 96 ? 95 : W - 1), 64, W>(w);
+      const uint32_t m1 = nonzero_mask<32, 63, 32, W>(w), m0 = nonzero_mask<0, 31, 0, W>(w);
+      return m3 ? 127 - (int)clz32(m3) : (m2 ? 95 - (int)clz32(m2) : (m1 ? 63 - (int)clz32(m1) : (m0 ? 31 - (int)clz32(m0) : -1)));
     }
 }
 

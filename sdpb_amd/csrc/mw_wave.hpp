@@ -151,7 +151,7 @@ template <int NX, int L> struct RsqrtFxW
 
 // mw::rsqrt(a) of the value lane `owner` (uniform) holds, computed by the whole wavefront and returned to every lane.
 // Bit-identical to mw::rsqrt<NL>.  a > 0.
-template <int NL> __device__ __forceinline__ Mw<NL> rsqrt(const Mw<NL> &a, int owner)
+template <int NL> __device__ __forceinline__ Mw<NL> rsqrt_lanes(const Mw<NL> &a, int owner)
 {
   static_assert(NL >= 4 && NL + 6 <= 64, "fixed-point path of mw::rsqrt; one limb per lane");
   constexpr int NX = NL + 2, L = NL + 1;
@@ -236,7 +236,7 @@ template <int NL> __device__ __forceinline__ Mw<NL> bcast(const Mw<NL> &a, int o
   return r;
 }
 // mw::rcp(a) of the value lane `owner` holds (a != 0), by the whole wavefront, returned to every lane; bit-identical
-template <int NL> __device__ __forceinline__ Mw<NL> rcp(const Mw<NL> &a, int owner)
+template <int NL> __device__ __forceinline__ Mw<NL> rcp_lanes(const Mw<NL> &a, int owner)
 {
   static_assert(NL >= 4 && NL + 6 <= 64, "fixed-point path of mw::rcp; one limb per lane");
   constexpr int NX = NL + 2, L = NL + 1;
@@ -261,6 +261,22 @@ template <int NL> __device__ __forceinline__ Mw<NL> rcp(const Mw<NL> &a, int own
   r.e = 1 + (int32_t)two - (int32_t)bcast((uint32_t)a.e, owner);
   r.neg = bcast(a.neg, owner);
   return r;
+}
+// Above 58 limbs (--precision 2048: 66) a number no longer fits the wavefront one limb per lane: every lane runs the
+// one-lane ladder on its own copy of the owner's value instead (same bits, the latency of round 3's chains).
+template <int NL> __device__ __forceinline__ Mw<NL> rsqrt(const Mw<NL> &a, int owner)
+{
+  if constexpr(NL + 6 <= 64)
+    return rsqrt_lanes<NL>(a, owner);
+  else
+    return mw::rsqrt<NL>(bcast(a, owner));
+}
+template <int NL> __device__ __forceinline__ Mw<NL> rcp(const Mw<NL> &a, int owner)
+{
+  if constexpr(NL + 6 <= 64)
+    return rcp_lanes<NL>(a, owner);
+  else
+    return mw::rcp<NL>(bcast(a, owner));
 }
 // mw::sqrt(a) of the value lane `owner` holds (a >= 0): the reciprocal square root together, the correction step
 // s = a r, s += r (a - s^2) / 2 by every lane on its own copy (four short dependent operations); bit-identical
