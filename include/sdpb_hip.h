@@ -39,7 +39,7 @@ typedef struct sdpb_hip_ctx sdpb_hip_ctx;
  * deterministic cost model (analogue of compute_block_grid_mapping.hxx:58-183);
  * rank/world_size describe this process (one process per GPU).  device_id < 0 keeps
  * the current device.  precision_bits is sdpb's --precision (Solver_Parameters.cxx:20-26): it is
- * rounded up to the next compiled mantissa width (128 ... 1536 bits; code 4 with a message naming
+ * rounded up to the next compiled mantissa width (128 ... 2048 bits; code 4 with a message naming
  * the range beyond that), as GMP rounds a precision up to whole limbs. */
 int sdpb_hip_create(int precision_bits, int num_blocks, const int *dims, const int *num_points, int N, int device_id,
                     int rank, int world_size, sdpb_hip_ctx **out);
@@ -145,7 +145,7 @@ int sdpb_hip_limbs(sdpb_hip_ctx *ctx);
  * compute_Q.cxx:107, Matrix_Normalizer.cxx:174-192; here, with FX = limbs - 2 rounded up to a multiple of
  * four, FB = 32 FX - 25 at --precision 400 ... 1024 (FX = 16, 24, 32, Toom-4 x Karatsuba image: 487 bits
  * at 400 ... 512, 743 at 640 ... 768, 999 at 1024), 32 FX - 17 above (Toom-4 image: 1263 bits at 1280,
- * 1519 at 1536) and 32 (limbs-2) - 7 at 128 and 256 bits (two Karatsuba levels)): inputs of
+ * 1519 at 1536, 2031 at 2048) and 32 (limbs-2) - 7 at 128 and 256 bits (two Karatsuba levels)): inputs of
  * sdpb_hip_op_int_syrk obey |v| < 2^FB. */
 int sdpb_hip_fx_frac_bits(sdpb_hip_ctx *ctx);
 /* Measurement aid (bench/profiling only, never on the solve path): average HIP-event time in

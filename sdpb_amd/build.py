@@ -13,14 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsdpb_hip.so")
-ALL_LIMBS = (6, 10, 16, 18, 24, 26, 34, 42, 50)  # 128, 256, 400/448, 512, 640-704, 768, 1024, 1280, 1536 bits
+ALL_LIMBS = (6, 10, 16, 18, 24, 26, 34, 42, 50, 66)  # 128, 256, 400/448, 512, 640-704, 768, 1024, 1280, 1536, 2048 bits
 # SDPB_LIMBS=18 builds a subset (developer iterations); the default builds every width.
 LIMBS = tuple(int(x) for x in os.environ["SDPB_LIMBS"].split(",")) if os.environ.get("SDPB_LIMBS") else ALL_LIMBS
 # Above 1024 bits the 32-column panel images of the chain kernels (k_chol_inv_lds: factor + inverse of a
 # diagonal block in LDS, 182 KB at 42 limbs; k_qsolve_panel2: 191 KB) exceed the CU's 160 KB of LDS, so those
 # widths are compiled with 16-column panels (every kernel and the host driver take the panel width from
 # SDPB_PB; each limb count is its own set of template instantiations).
-EXTRA_FLAGS = {42: ["-DSDPB_PB=16"], 50: ["-DSDPB_PB=16"]}
+EXTRA_FLAGS = {42: ["-DSDPB_PB=16"], 50: ["-DSDPB_PB=16"], 66: ["-DSDPB_PB=16"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-Wno-unused-result", "-Wno-pass-failed"]

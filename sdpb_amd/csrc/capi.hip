@@ -138,7 +138,8 @@ int sdpb_hip_create_with_costs(int precision_bits, int num_blocks, const int *di
       };
       const Entry table[] = {{6, sdpb::make_solver_6},   {10, sdpb::make_solver_10}, {16, sdpb::make_solver_16},
                              {18, sdpb::make_solver_18}, {24, sdpb::make_solver_24}, {26, sdpb::make_solver_26},
-                             {34, sdpb::make_solver_34}, {42, sdpb::make_solver_42}, {50, sdpb::make_solver_50}};
+                             {34, sdpb::make_solver_34}, {42, sdpb::make_solver_42}, {50, sdpb::make_solver_50},
+                             {66, sdpb::make_solver_66}};
       for(const Entry &e : table)
         if(want <= e.limbs && e.make)
           {
@@ -147,7 +148,7 @@ int sdpb_hip_create_with_costs(int precision_bits, int num_blocks, const int *di
           }
       if(!s)
         return fail(nullptr, 4, "sdpb_hip_create: no compiled mantissa width covers --precision " + std::to_string(precision_bits)
-                                   + ": this library is built for 128 ... 1536 bits (limb counts 6, 10, 16, 18, 24, 26, 34, 42, 50; "
+                                   + ": this library is built for 128 ... 2048 bits (limb counts 6, 10, 16, 18, 24, 26, 34, 42, 50, 66; "
                                      "sdpb_amd/build.py, ALL_LIMBS)");
       ctx->solver.reset(s);
       *out = ctx.release();

@@ -4201,6 +4201,16 @@ __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TRI_WAVES : 1024 / T) k_tri
 // Newton iteration for lambda_min of the tridiagonal (D, E2 = offdiag^2) from below,
 // working at WL limbs (operands are narrowed on load).  Monotone from below in exact
 // arithmetic; quadratically convergent.
+// Round 5: the leading principal minors p_i = det(T_i - x) and their derivatives by the three-term recurrence
+//   p_{i+1} = (d_i - x) p_i - e_i^2 p_{i-1},   p'_{i+1} = (d_i - x) p'_i - p_i - e_i^2 p'_{i-1}
+// -- four products and two normalisations per row instead of a reciprocal (five to seven products deep) and three
+// products; ONE reciprocal per Newton step.  The exponent of Mw is an int32: the minors of a 40 x 40 matrix cannot leave
+// it.  x below the spectrum <=> every p_i > 0.  Each step of the recurrence is one rounding of (d_i - x) and of e_i^2,
+// as in the quotient form.  k_tridiag_min 2.37 -> 1.99 ms per launch on C4 (profiles/r05_tridiag_min.txt: 0.68 ms of it
+// are the fp64 bisection, 0.58 / 0.34 / 0.40 ms the 6-, 10- and 18-limb rungs); -DSDPB_TRIMIN_POLY=0: the quotient form.
+#ifndef SDPB_TRIMIN_POLY
+#define SDPB_TRIMIN_POLY 1
+#endif
 template <int WL, int NL>
 __device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t oe, int n, Mw<WL> &x, double span, int emax,
                                int backoff_bits)
@@ -4211,6 +4221,37 @@ __device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t
     {
       Mw<WL> S = mw::zero<WL>(), inv = mw::zero<WL>(), tq = mw::zero<WL>();
       bool overshoot = false;
+#if SDPB_TRIMIN_POLY
+      {
+        Mw<WL> pm = mw::from_i32<WL>(1), pmm = mw::zero<WL>(), dpm = mw::zero<WL>(), dpmm = mw::zero<WL>();
+        for(int i = 0; i < n; ++i)
+          {
+            const Mw<WL> di = mw::sub(mw::narrow<WL, NL>(mw::load<NL>(D.p, od + i)), x);
+            Acc<WL> ap = mw::acc_zero<WL>(), ad = mw::acc_zero<WL>();
+            mw::acc_fma(ap, di, pm);
+            mw::acc_fma(ad, di, dpm);
+            mw::acc_add(ad, pm, 1u);
+            if(i >= 1)
+              {
+                const Mw<WL> e2 = mw::narrow<WL, NL>(mw::load<NL>(E.p, oe + i));
+                mw::acc_fms(ap, e2, pmm);
+                mw::acc_fms(ad, e2, dpmm);
+              }
+            const Mw<WL> pi = mw::acc_result(ap);
+            if(pi.neg || mw::is_zero(pi))
+              {
+                overshoot = true;
+                break;
+              }
+            pmm = pm;
+            dpmm = dpm;
+            pm = pi;
+            dpm = mw::acc_result(ad);
+          }
+        if(!overshoot && !mw::is_zero(dpm))
+          S = mw::mul(dpm, mw::rcp(pm)); // p'/p = sum_i q_i'/q_i
+      }
+#else
       for(int i = 0; i < n; ++i)
         {
           Mw<WL> qi = mw::sub(mw::narrow<WL, NL>(mw::load<NL>(D.p, od + i)), x), qp = minus_one;
@@ -4229,6 +4270,7 @@ __device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t
           tq = mw::mul(qp, inv);
           S = mw::add(S, tq);
         }
+#endif
       if(overshoot)
         {
           // Newton from below never crosses the root in exact arithmetic: a non-positive

@@ -3014,4 +3014,5 @@ __attribute__((weak)) SolverBase *make_solver_26(int, const std::vector<int> &, 
 __attribute__((weak)) SolverBase *make_solver_34(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
 __attribute__((weak)) SolverBase *make_solver_42(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
 __attribute__((weak)) SolverBase *make_solver_50(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
+__attribute__((weak)) SolverBase *make_solver_66(int, const std::vector<int> &, const std::vector<int> &, int, int, int, const std::vector<long long> &);
 } // namespace sdpb

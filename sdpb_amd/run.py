@@ -33,8 +33,8 @@ def _options(argv: Optional[List[str]] = None):
     ap.add_argument("-s", "--sdpDir", required=True)
     ap.add_argument("-o", "--outDir", default=None, help="default: <sdpDir>_out")
     ap.add_argument("--precision", type=int, default=400,
-                    help="bits of the mantissa, rounded up to the next compiled width (128, 256, 448, 512, 704, 768, 1024, 1280, 1536: "
-                         "GMP rounds up to whole limbs too, Solver_Parameters.cxx:26); above 1536 the library refuses with a message "
+                    help="bits of the mantissa, rounded up to the next compiled width (128, 256, 448, 512, 704, 768, 1024, 1280, 1536, 2048: "
+                         "GMP rounds up to whole limbs too, Solver_Parameters.cxx:26); above 2048 the library refuses with a message "
                          "naming this range (the reference accepts any precision).  The exact integer Q' is formed from a fixed-point "
                          "image of at least precision - 32 bits (sdpb_hip_fx_frac_bits); pass precision + 64 for at least `precision`")
     ap.add_argument("--maxSharedMemory", default="0",

@@ -57,7 +57,7 @@ def algorithmic_bytes_per_iteration(dims, num_points, N, bytes_per_number: int) 
 # The arrays Solver::build_layout (csrc/solver.hpp) allocates, from the shapes alone, so that a launcher can refuse a
 # plan that cannot fit BEFORE anything is uploaded (the reference estimates its memory per node the same way before it
 # allocates: run.cxx:79-181).  tests/test_gpu_parity_at_size.py compares it with sdpb_hip_memory_plan on the device.
-COMPILED_LIMBS = (6, 10, 16, 18, 24, 26, 34, 42, 50)
+COMPILED_LIMBS = (6, 10, 16, 18, 24, 26, 34, 42, 50, 66)
 HBM_BYTES = 288 * 10 ** 9
 
 

@@ -273,7 +273,7 @@ def test_emulated_memory_plan_and_max_shared_memory():
 
 
 # widest --precision each compiled limb count serves (limbs = 2 floor((p + 127) / 64), GMP's allocation)
-TOP_PRECISION = {6: 128, 10: 256, 16: 448, 18: 512, 24: 704, 26: 768, 34: 1024, 42: 1280, 50: 1536}
+TOP_PRECISION = {6: 128, 10: 256, 16: 448, 18: 512, 24: 704, 26: 768, 34: 1024, 42: 1280, 50: 1536, 66: 2048}
 
 
 @pytest.mark.parametrize("limbs", [6, 18, 24, 26, 34, 42])

@@ -16,7 +16,7 @@ def _solver(sdp, precision, params=None):
 
 
 # ---- arithmetic: device ops vs GMP mpf (oracle), tolerance 2 ulp of the device mantissa
-@pytest.mark.parametrize("precision", [128, 256, 512, 768, 1024, 1280, 1536])
+@pytest.mark.parametrize("precision", [128, 256, 512, 768, 1024, 1280, 1536, 2048])
 def test_device_arithmetic_matches_mpf(precision):
     from oracle.oracle import Oracle
     sdp, _, _, _ = parity.load_case("1d")
@@ -37,7 +37,7 @@ def test_device_arithmetic_matches_mpf(precision):
 
 
 # ---- the syrk_Q stage as an operator: calculate_matrix_square.test.cxx recipe + saturated columns
-@pytest.mark.parametrize("precision", [128, 256, 400, 512, 664, 768, 1024, 1280, 1536])
+@pytest.mark.parametrize("precision", [128, 256, 400, 512, 664, 768, 1024, 1280, 1536, 2048])
 def test_syrk_Q_stage_and_saturated_columns(precision):
     sdp, _, _, _ = parity.load_case("1d")
     s = _solver(sdp, precision)
@@ -52,7 +52,7 @@ def test_config_C1_at_its_stated_precision_128():
 
 
 # ---- above 1024 bits (the reference accepts any --precision, Solver_Parameters.cxx:20-26)
-@pytest.mark.parametrize("precision,limbs", [(1100, 42), (1280, 42), (1536, 50)])
+@pytest.mark.parametrize("precision,limbs", [(1100, 42), (1280, 42), (1536, 50), (1700, 66), (2048, 66)])
 def test_iterations_above_1024_bits(precision, limbs):
     from oracle.oracle import Oracle
     sdp, meta, _, _ = parity.load_case("1d-constraints")
@@ -85,15 +85,15 @@ def test_iterations_at_the_default_precision_400():
 def test_precision_beyond_the_compiled_widths_is_a_clear_error():
     from sdpb_amd.solver import SDPBError
     sdp, _, _, _ = parity.load_case("1d")
-    with pytest.raises(SDPBError, match="built for 128 ... 1536 bits"):
-        _solver(sdp, 1700)
+    with pytest.raises(SDPBError, match="built for 128 ... 2048 bits"):
+        _solver(sdp, 2100)
 
 
 # ---- the dominant kernel: fixed-point syrk is bit exact (integers)
 @pytest.mark.parametrize("precision,rows,cols,splits", [(128, 37, 21, None), (512, 300, 50, None), (512, 9, 1, None),
                                                         (1024, 64, 33, None), (512, 300, 50, "4"), (256, 100, 40, "16"),
                                                         (768, 130, 40, "3"), (1024, 200, 33, "2"), (1280, 64, 33, None),
-                                                        (1536, 90, 20, "2"), (400, 50, 20, None),
+                                                        (1536, 90, 20, "2"), (400, 50, 20, None), (2048, 90, 20, "2"), (2048, 64, 33, None),
                                                         (664, 64, 33, "2"),
                                                         # k_syrk_fx3 (32 x 32 tiles, 2 x 2 outputs per lane): odd widths (pair loads at
                                                         # 8-byte alignment, second column of the last pair past N), every quadrant mask
@@ -150,7 +150,7 @@ def test_int_syrk_in_chunks_under_a_memory_budget_is_bit_exact(precision, rows, 
     s.close()
 
 
-@pytest.mark.parametrize("limbs,precision", [(6, 128), (10, 256), (16, 448), (18, 512), (24, 704), (26, 768), (34, 1024), (42, 1280), (50, 1536)])
+@pytest.mark.parametrize("limbs,precision", [(6, 128), (10, 256), (16, 448), (18, 512), (24, 704), (26, 768), (34, 1024), (42, 1280), (50, 1536), (66, 2048)])
 def test_Q_image_keeps_at_least_precision_minus_32_bits(limbs, precision):
     """The floor under the fixed-point image of P' the exact integer Q' = P'^T P' is formed from, at the widest --precision
     every compiled limb count serves (the reference truncates P' at 2^precision: Matrix_Normalizer.cxx:174-192,
@@ -161,7 +161,7 @@ def test_Q_image_keeps_at_least_precision_minus_32_bits(limbs, precision):
     s = _solver(sdp, precision)
     assert s.limbs == limbs
     assert s.fx_frac_bits >= precision - 32, (precision, s.fx_frac_bits)
-    wider = _solver(sdp, precision + 64) if precision + 64 <= 1536 else None
+    wider = _solver(sdp, precision + 64) if precision + 64 <= 2048 else None
     if wider is not None:
         assert wider.fx_frac_bits >= precision, (precision + 64, wider.fx_frac_bits)   # the documented way to a full-width image
         wider.close()
