@@ -184,16 +184,24 @@ def parity_gate(solver, workload: str, scale: float, precision: int):
     # regression that loses hundreds of bits but stays inside 2^-(p/2) is still refused a value.
     tol_bits = precision // 2
     thr_path = os.path.join(os.path.dirname(path), "gate_thresholds.json")
+    early = None          # (n, bits): a tighter bar for the first n iterations (the ones the clock sees), "<fixture>#first<n>"
     if os.path.exists(thr_path):
         with open(thr_path) as f:
-            tol_bits = max(tol_bits, int(json.load(f).get(os.path.basename(path), tol_bits)))
-    worst, bad_all = float("-inf"), []
+            thr = json.load(f)
+        tol_bits = max(tol_bits, int(thr.get(os.path.basename(path), tol_bits)))
+        for key, bits in thr.items():
+            if key.startswith(os.path.basename(path) + "#first"):
+                early = (int(key.split("#first")[1]), int(bits))
+    worst, bad_all, by_iteration = float("-inf"), [], []
     for rec in fx["iterations"]:
         if solver.iterate():
             bad_all.append((rec["iteration"], "terminated: " + solver.terminate_reason))
             break
         bad, w = parity.compare_iteration(solver.scalars(), rec, tol_bits=tol_bits)
         worst = max(worst, w)
+        by_iteration.append(round(w, 1))
+        if early and rec["iteration"] <= early[0] and w > -early[1] and not bad:
+            bad_all.append((rec["iteration"], [("worst field of an early iteration", w, -early[1])]))
         if bad:
             bad_all.append((rec["iteration"], bad))
     terminated = None
@@ -212,6 +220,9 @@ def parity_gate(solver, workload: str, scale: float, precision: int):
                     bad_all.append((fx["terminated_in_iteration"], [(key, w)]))
     return {"fixture": os.path.relpath(path, ROOT), "iterations": len(fx["iterations"]), "tolerance_log2_rel": -tol_bits,
             "worst_log2_rel": worst, "passed": not bad_all, "violations": bad_all[:4], "followed_to_termination": terminated,
+            "worst_log2_rel_by_iteration": by_iteration,
+            "early_iterations_bar": ({"first": early[0], "tolerance_log2_rel": -early[1],
+                                      "worst_log2_rel": max(by_iteration[:early[0]]) if by_iteration else None} if early else None),
             "fields": "mu P-obj D-obj gap P-err p-err D-err R-err P-step D-step beta Q_cond_number max_block_cond_number"}
 
 
