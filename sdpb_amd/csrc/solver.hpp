@@ -2259,9 +2259,19 @@ private:
       if(!count)
         return;
       lanes = std::min(512, lanes * widen);
-      if(lanes >= 512)
-        launch(k_tridiag<NL, 512>, dim3(count), dim3(512), stream_, psd(W), vecn(D), vecn(E), ids);
-      else if(lanes >= 256)
+      // (above 66 limbs the tree image of 512 lanes no longer fits the CU's 160 KB of LDS: 256 lanes there.  A 98-limb
+      // build -- 3072 bits, 50 minutes of hipcc for the one object -- was tried in round 5: every kernel fits, but the step
+      // lengths and the block condition numbers agree with the oracle to 2^-64 only; not shipped, profiles/r05w_*.log)
+      constexpr bool T512 = 512 * sizeof(TriSlot<NL>) + sizeof(Mw<NL>) <= 160 * 1024;
+      if constexpr(T512)
+        {
+          if(lanes >= 512)
+            {
+              launch(k_tridiag<NL, 512>, dim3(count), dim3(512), stream_, psd(W), vecn(D), vecn(E), ids);
+              return;
+            }
+        }
+      if(lanes >= 256)
         launch(k_tridiag<NL, 256>, dim3(count), dim3(256), stream_, psd(W), vecn(D), vecn(E), ids);
       else if(lanes >= 128)
         launch(k_tridiag<NL, 128>, dim3(count), dim3(128), stream_, psd(W), vecn(D), vecn(E), ids);

@@ -42,7 +42,9 @@ C5_SLICE = dict(dims=[6] * 24, num_points=[2] * 24, N=72, precision=1024, seed=5
 
 LIVE = [("C3 full size", _shape("C3"), 3),                      # J=600, N=100: 4 Q panels, 28 syrk tiles x 16 splits
         ("C4 x0.25", _shape("C4", 0.25), 3),                    # J=150, N=250: 8 Q panels, m=2 blocks with 4 panels
-        ("C5 slice", C5_SLICE, 3)]
+        ("C5 slice", C5_SLICE, 3),
+        # the widest compiled mantissa (66 limbs, 16-column panels, one-lane roots): N = 40 is three panels of Cholesky(Q)
+        ("2048-bit slice", dict(dims=[6] * 12, num_points=[2] * 12, N=40, precision=2048, seed=6), 2)]
 
 
 @pytest.mark.parametrize("name,c,iters", LIVE, ids=[x[0] for x in LIVE])
