@@ -43,3 +43,51 @@ def test_bench_under_the_drivers_launcher_and_single_rank_agree():
     with mpmath.workprec(400):   # local: other tests rely on the precision tests/parity.py sets
         a, b = mpmath.mpf(two["P-obj"]), mpmath.mpf(one["P-obj"])
         assert b != 0 and abs(a - b) <= mpmath.mpf(2) ** -200 * abs(b)   # rank-order sums differ in the last bits only
+
+
+class _Replay:
+    """A stand-in for SDPSolver that replays a fixture (optionally with one field of one iteration perturbed): the gate's
+    own logic is what is under test here, no device, no library."""
+
+    def __init__(self, fx, perturb=None, wrong_reason=False):
+        self.fx, self.k, self.perturb, self.wrong_reason = fx, 0, perturb, wrong_reason
+        self.sdp = type("S", (), {"N": fx["N"], "J": fx["J"]})()
+        self.terminate_reason = ""
+
+    def iterate(self):
+        if self.k >= len(self.fx["iterations"]):
+            self.terminate_reason = "maxIterations exceeded" if self.wrong_reason else self.fx["terminate_reason"]
+            return True
+        self.k += 1
+        return False
+
+    def scalars(self):
+        import mpmath
+        rec = dict(self.fx["iterations"][self.k - 1])
+        if self.perturb and self.perturb[0] == self.k:
+            mpmath.mp.prec = 1200
+            rec["mu"] = mpmath.nstr(mpmath.mpf(rec["mu"]) * (1 + mpmath.mpf(2) ** -self.perturb[1]), 330)
+        return rec
+
+    def scalar(self, key):
+        return self.fx[key]
+
+
+def test_parity_gate_of_the_bench_covers_every_timed_iteration_and_the_termination():
+    """bench.py's gate on the full-size C4 fixture (round 5: 48 oracle iterations + 'maxComplementarity exceeded' in iteration
+    49): a faithful replay passes and is followed to termination; a field that is 2^-260 off in an EARLY iteration fails the
+    tighter bar of the iterations the clock sees although it is inside the whole-run floor 2^-256; the same error late passes;
+    2^-250 anywhere fails; a different terminate reason fails."""
+    sys.path.insert(0, libs.ROOT)
+    import bench
+    with open(bench.fixture_path("C4", 1.0)) as f:
+        fx = json.load(f)
+    assert len(fx["iterations"]) == 48 and fx["terminated_in_iteration"] == 49 and fx["terminate_reason"] == "maxComplementarity exceeded"
+    assert len(fx["iterations"]) >= 25          # the driver's K + W (20 + 5) and the default invocation (4 + 1) are inside it
+    g = bench.parity_gate(_Replay(fx), "C4", 1.0, 512)
+    assert g["passed"] and g["iterations"] == 48 and g["followed_to_termination"] == {"iteration": 49, "reason": "maxComplementarity exceeded"}
+    assert len(g["worst_log2_rel_by_iteration"]) == 48 and g["early_iterations_bar"]["first"] == 25
+    assert not bench.parity_gate(_Replay(fx, perturb=(7, 260)), "C4", 1.0, 512)["passed"]
+    assert bench.parity_gate(_Replay(fx, perturb=(40, 260)), "C4", 1.0, 512)["passed"]
+    assert not bench.parity_gate(_Replay(fx, perturb=(40, 250)), "C4", 1.0, 512)["passed"]
+    assert not bench.parity_gate(_Replay(fx, wrong_reason=True), "C4", 1.0, 512)["passed"]
