@@ -104,7 +104,7 @@ def cpu_baseline(cfg_name: str, precision: int, seconds_budget: float = 45.0, fu
     cores = usable_cpus()   # cgroup quota and affinity, not just the logical CPU count
     scale = 1.0 if full else float(os.environ.get("SDPB_BENCH_CPU_SCALE", "0.5"))
     c = synthetic.config(cfg_name, scale)
-    sdp, src = synthetic.make_lazy(c["dims"], c["num_points"], c["N"], precision, c["seed"])
+    sdp, src = synthetic.make_lazy(c["dims"], c["num_points"], c["N"], precision, c["seed"], feasible=c.get("feasible", False))
     t_setup = time.time()
     o = Oracle(sdp, precision, param_prec=0, threads=cores, block_source=src)
     t_setup = time.time() - t_setup
@@ -263,7 +263,7 @@ def dry_run(args, lib, rank, world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = synthetic.config(args.workload, args.scale)
-    sdp, source = synthetic.make_lazy(cfg["dims"], cfg["num_points"], cfg["N"], cfg["precision"], cfg["seed"])
+    sdp, source = synthetic.lazy(cfg)
     solver = SDPSolver(sdp, cfg["precision"], rank=rank, world_size=world, upload_all_blocks=False, block_source=source,
                        lib_path=lib)
     if world > 1:
@@ -354,7 +354,8 @@ def emit(record):
 
 def load_workload(args):
     """-> (label, sdp, block_source or None, precision, params, gate_records or None, gate_fixture)
-    `C3`, `C4`, `C5slice` (+ --scale): the synthetic SDPs of SURVEY.md §8d with their committed oracle fixtures;
+    `C3`, `C4`, `C5slice`, `C5` (full: one 288-GB GPU holds it since round 6), `C4f` (C4's shape, strictly feasible: ends with
+    "found primal-dual optimal solution") (+ --scale): the synthetic SDPs of SURVEY.md §8d with their committed oracle fixtures;
     `golden:<case>`: one of the reference's own end-to-end SDPs (tests/golden/<case>/sdp, e.g. golden:singlet_cT =
     test/data/end-to-end_tests/SingletScalar_cT_test_nmax6/primal_dual_optimal — the only SDP the reference publishes
     a speed for: BASELINE.md §1), run with the parameter values of the reference run (tests/golden/exact_params.json)
@@ -370,7 +371,7 @@ def load_workload(args):
                 f"P_tot={sdp.P_total}, --precision {meta['precision']}", sdp, None, meta["precision"], params,
                 {"iterations": iters, "out": out, "tol_bits": 99}, f"tests/golden/{name}/iterations.json")
     cfg = synthetic.config(args.workload, args.scale)
-    sdp, source = synthetic.make_lazy(cfg["dims"], cfg["num_points"], cfg["N"], cfg["precision"], cfg["seed"])
+    sdp, source = synthetic.lazy(cfg)
     kind = "3d-Ising mixed-correlator" if args.workload == "C4" else "stress" if args.workload.startswith("C5") else "bootstrap-shaped"
     label = (f"{args.workload}: synthetic {kind} SDP (SURVEY.md §8d), J={sdp.J}, N={sdp.N}, P_tot={sdp.P_total}, "
              f"--precision {cfg['precision']}" + ("" if args.scale == 1.0 else f" [scaled x{args.scale}]"))
@@ -480,14 +481,17 @@ def main():
     # not minutes later inside an allocation (full C5 on fewer than four GPUs, say).
     from sdpb_amd.solver import plan_blocks
     owners = plan_blocks(sdp.dims, sdp.num_points, sdp.N, sim or world, lib_path=args.lib)
+    # the device's own figures, so that the plan follows the library's rule for the windows of the Q stage (round-5 advisor)
+    free_b, total_b = torch.cuda.mem_get_info(device)
     planned = workmodel.planned_footprint(sdp.dims, sdp.num_points, sdp.N, precision, owners, rank,
                                           sim or world, dist_cholq=os.environ.get("SDPB_HIP_DIST_CHOLQ") == "1",
-                                          max_shared_bytes=int(float(os.environ.get("SDPB_HIP_SYRK_PART_BYTES", "0"))))
-    free_b, total_b = torch.cuda.mem_get_info(device)
+                                          num_cus=torch.cuda.get_device_properties(device).multi_processor_count,
+                                          hbm_bytes=total_b, free_bytes=free_b)
+    _not_bytes = ("total", "rows", "owned_blocks", "image_chunks", "image_rows_per_chunk")
     print(f"[bench rank {rank}/{world}] planned HBM footprint {planned['total'] / 1e9:.2f} GB of {total_b / 1e9:.0f} GB "
-          f"({free_b / 1e9:.0f} GB free): " + ", ".join(f"{k} {v / 1e9:.2f}" for k, v in planned.items()
-                                                        if k not in ("total", "rows", "owned_blocks")) +
-          f"; {planned['owned_blocks']} blocks, {planned['rows']} rows", file=sys.stderr, flush=True)
+          f"({free_b / 1e9:.0f} GB free): " + ", ".join(f"{k} {v / 1e9:.2f}" for k, v in planned.items() if k not in _not_bytes) +
+          f"; {planned['owned_blocks']} blocks, {planned['rows']} rows, the image of P' in {planned['image_chunks']} row window(s) of "
+          f"{planned['image_rows_per_chunk']} rows", file=sys.stderr, flush=True)
     if planned["total"] > free_b and not share:
         raise SystemExit(f"bench.py rank {rank}: the planned footprint {planned['total'] / 1e9:.1f} GB exceeds the {free_b / 1e9:.1f} GB free on "
                          f"device {local_rank}: use more GPUs (--gpus) or a smaller workload")
@@ -715,6 +719,8 @@ def main():
                          # splits per tile and their length -- above P_tot = 81 920 rows the "<= 2560 rows per split" rule that
                          # keeps the operand panels in L2 stops holding (32 splits at most) and this shows it
                          "syrk_plan": mem_plan["syrk"],
+                         # the input window: rows of P' whose fixed-point image is resident at a time (solver.hpp: q_window)
+                         "image_plan": mem_plan.get("image"),
                          # fraction bits of the fixed-point image of P' the exact integer product is formed from, beside the
                          # reference's (Matrix_Normalizer.cxx:174-192 truncates at 2^precision)
                          "q_image_bits": solver.fx_frac_bits, "reference_bits": precision},

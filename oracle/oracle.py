@@ -41,6 +41,7 @@ def lib():
         L.orc_set_block.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_char_p] * 4
         L.orc_set_block_f64.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.orc_set_block_c.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p]
         L.orc_set_objective.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
         L.orc_init_state.argtypes = [ctypes.c_void_p]
         L.orc_iterate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
@@ -133,10 +134,13 @@ class Oracle:
             for j in range(J):
                 be, bo, Bv, cv = block_source(j)
                 Bv = np.ascontiguousarray(Bv, dtype=np.float64)
-                cv = np.ascontiguousarray(cv, dtype=np.float64)
+                c_text = list(cv) if len(cv) and isinstance(cv[0], str) else None   # feasible family: c is no double
+                cv = np.zeros(len(cv)) if c_text else np.ascontiguousarray(cv, dtype=np.float64)
                 flat = lambda rows: " ".join(" ".join(r) for r in rows).encode()
                 self._chk(self.L.orc_set_block_f64(self.h, j, flat(be), flat(bo), Bv.ctypes.data_as(dp),
                                                    cv.ctypes.data_as(dp)))
+                if c_text:
+                    self._chk(self.L.orc_set_block_c(self.h, j, " ".join(c_text).encode()))
         else:
             for j, blk in enumerate(sdp.blocks):
                 self._chk(self.L.orc_set_block(self.h, j, *block_text(blk)))

@@ -1438,6 +1438,17 @@ int orc_set_threads(int n)
 #endif
 }
 
+// GMP's default precision is process-global and mpf_init reads it (as does syrk_Q's truncation point,
+// compute_Q.cxx:107 = mpf_get_default_prec).  Every entry point therefore re-establishes the precision of ITS
+// oracle first: oracles of different precisions may be alive at once without contaminating each other
+// (round-5 review: a 512-bit oracle created before a 1536-bit one silently computed at 1536 bits).
+static inline Oracle *enter(void *h)
+{
+  Oracle *o = static_cast<Oracle *>(h);
+  mpf_set_default_prec(o->prec);
+  return o;
+}
+
 void *orc_create(int precision_bits, int J, const int *dims,
                  const int *num_points, int N)
 {
@@ -1507,7 +1518,7 @@ const char *orc_last_error(void *h)
 // minPrimalStep, minDualStep}; prec_bits=0 -> working precision.
 int orc_set_param(void *h, const char *name, const char *value, int prec_bits)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   Params &p = o->par;
   const std::string n(name);
@@ -1535,7 +1546,7 @@ int orc_set_flags(void *h, long max_iterations, int find_primal_feasible,
                   int find_dual_feasible, int detect_primal_feasible_jump,
                   int detect_dual_feasible_jump)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   o->par.max_iterations = max_iterations;
   o->par.find_primal_feasible = find_primal_feasible;
   o->par.find_dual_feasible = find_dual_feasible;
@@ -1549,7 +1560,7 @@ int orc_set_flags(void *h, long max_iterations, int find_primal_feasible,
 int orc_set_block(void *h, int j, const char *bases_even,
                   const char *bases_odd, const char *B, const char *c)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   Block &bl = o->blk.at(j);
   std::vector<F> tmp;
@@ -1583,7 +1594,7 @@ int orc_set_block(void *h, int j, const char *bases_even,
 int orc_set_block_f64(void *h, int j, const char *bases_even,
                       const char *bases_odd, const double *B, const double *c)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   Block &bl = o->blk.at(j);
   // bases through the text path (shared code), B and c below
@@ -1615,9 +1626,20 @@ int orc_set_block_f64(void *h, int j, const char *bases_even,
   ORC_CATCH(o)
 }
 
+// c of block j as decimals (after orc_set_block_f64: the feasible synthetic family has dyadic B but a c that
+// is no double, sdpb_amd/synthetic.py)
+int orc_set_block_c(void *h, int j, const char *c)
+{
+  Oracle *o = enter(h);
+  ORC_TRY(o)
+  Block &bl = o->blk.at(j);
+  parse_list(c, bl.c, bl.P, "c");
+  ORC_CATCH(o)
+}
+
 int orc_set_objective(void *h, const char *b, const char *constant)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   parse_list(b, o->b, o->N, "b");
   o->objective_const = from_str(constant);
@@ -1627,7 +1649,7 @@ int orc_set_objective(void *h, const char *b, const char *constant)
 // SDP_Solver.cxx:23-38 : x=0, y=0, X = Omega_p I, Y = Omega_d I
 int orc_init_state(void *h)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   for(auto &bl : o->blk)
     {
@@ -1658,7 +1680,7 @@ int orc_init_state(void *h)
 // save_solution would print.  Returns nonzero on error (orc_last_error).
 int orc_iterate(void *h, int *terminated)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   *terminated = 0;
   o->iteration += 1;
@@ -1694,7 +1716,7 @@ int orc_iterate(void *h, int *terminated)
 // exposes that as sdpb_hip_schur_solver_init / sdpb_hip_schur_solve; this is the checker.
 int orc_schur_solver_init(void *h)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   cholesky_decomposition(*o, true);
   cholesky_decomposition(*o, false);
@@ -1716,7 +1738,7 @@ int orc_schur_solver_init(void *h)
 // (set with orc_set_array), out the solution in the same arrays
 int orc_schur_solve(void *h)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   solve_schur_complement_equation(*o);
   ORC_CATCH(o)
@@ -1724,7 +1746,7 @@ int orc_schur_solve(void *h)
 // which in {"x","X","y","Y","dx","dy"}: column-major decimals (state injection / right-hand sides)
 int orc_set_array(void *h, const char *which, int j, int parity, const char *txt)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   const std::string w(which);
   std::vector<F> v;
@@ -1769,7 +1791,7 @@ const char *orc_terminate_string(void *h)
 // out.txt keys (save_solution.cxx:32-37)
 const char *orc_get_scalar(void *h, const char *name)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   const std::string n(name);
   const F *v = nullptr;
   F pe;
@@ -1799,7 +1821,7 @@ const char *orc_get_scalar(void *h, const char *name)
 // whitespace separated.  j/parity ignored where not applicable.
 const char *orc_get_array(void *h, const char *which, int j, int parity)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   const std::string w(which);
   std::ostringstream ss;
   auto dumpv = [&](const std::vector<F> &v) {
@@ -1851,7 +1873,7 @@ static void put_record(const F &f, uint64_t *rec, int limbs64)
 // or any orc_get_array name (column-major).  Returns the element count; writes when capacity allows.
 long orc_get_records(void *h, const char *which, int j, int parity, int limbs64, uint64_t *out, long capacity)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   const std::string w(which);
   std::vector<const F *> v;
   auto rowmajor = [&](const Mat &m) {
@@ -1896,7 +1918,7 @@ long orc_get_records(void *h, const char *which, int j, int parity, int limbs64,
 // it does when it was written by an oracle of the same precision with limbs64 >= that count.
 int orc_set_records(void *h, const char *which, int j, int parity, int limbs64, const uint64_t *in, long count)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   ORC_TRY(o)
   const std::string w(which);
   std::vector<F> *dst = nullptr;
@@ -1932,7 +1954,7 @@ int orc_set_records(void *h, const char *which, int j, int parity, int limbs64, 
 // (column-major N x N, lower part zero).
 const char *orc_int_syrk(void *h, int rows, int cols, const char *Ptxt)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   std::vector<Z> P((size_t)rows * cols);
   std::istringstream in(Ptxt);
   std::string tok;
@@ -1964,7 +1986,7 @@ const char *orc_int_syrk(void *h, int rows, int cols, const char *Ptxt)
 // Solver_Parameters before --precision is applied), as an exact decimal expansion.
 const char *orc_parse_exact(void *h, const char *value, int prec_bits)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   F v = from_str(value, prec_bits ? prec_bits : 0);
   // exact rational n / 2^k (mpq_set_f is exact); the caller expands it in decimal
   mpq_t q;
@@ -1982,7 +2004,7 @@ const char *orc_parse_exact(void *h, const char *value, int prec_bits)
 // {"add","sub","mul","div","sqrt"}; operands/results decimal strings.
 const char *orc_scalar_op(void *h, const char *op, const char *a, const char *b)
 {
-  Oracle *o = static_cast<Oracle *>(h);
+  Oracle *o = enter(h);
   F x = from_str(a), y = from_str(b), r;
   const std::string s(op);
   if(s == "add") r = x + y;

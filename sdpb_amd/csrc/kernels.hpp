@@ -2488,7 +2488,8 @@ __global__ void __launch_bounds__(WG) k_normalize_fx(mw::CPtr PT, size_t count, 
 
 // the same image from staged planes: plane 0 = sign, planes 1..FX = |v| (sdpb_hip_op_int_syrk);
 // in and out are distinct buffers
-template <int FX> __global__ void __launch_bounds__(WG) k_fx_from_int(const uint32_t *in, size_t count, uint32_t *fx, size_t fx_stride)
+// (in_stride = elements per staged plane; `in` may point at a row window of the staged matrix)
+template <int FX> __global__ void __launch_bounds__(WG) k_fx_from_int(const uint32_t *in, size_t in_stride, size_t count, uint32_t *fx, size_t fx_stride)
 {
   const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
   if(idx >= count)
@@ -2496,7 +2497,7 @@ template <int FX> __global__ void __launch_bounds__(WG) k_fx_from_int(const uint
   uint32_t v[FX];
 #pragma unroll
   for(int i = 0; i < FX; ++i)
-    v[i] = in[(size_t)(i + 1) * count + idx];
+    v[i] = in[(size_t)(i + 1) * in_stride + idx];
   fx_store<FX>(v, in[idx] != 0, fx, fx_stride, idx);
 }
 
@@ -3887,6 +3888,27 @@ __global__ void __launch_bounds__(WG) k_syrk3_sum_splits(uint32_t *part, int nsp
 
 template <int FX> constexpr int syrk_waves_per_simd() { return fx_toom4k<FX>() ? SDPB_SYRK3_WAVES : SDPB_SYRK_WAVES; }
 
+// dst += src on the lower triangle (i >= j) and on the N column sums behind the N x N block: the partial G of two
+// INPUT windows (row chunks of the fixed-point image; the reference loops over its input windows in
+// bigint_syrk_blas.cxx:239-285 and lets BLAS accumulate into the output window) are plain non-negative integers
+// of W planes, so they add exactly -- the same sum the cross-GPU all-reduce forms over the ranks' rows.
+template <int W> __global__ void __launch_bounds__(WG) k_acc_add_tri(uint32_t *dst, const uint32_t *src, size_t stride, int N)
+{
+  const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x;
+  if(idx >= (size_t)N * N + N)
+    return;
+  if(idx < (size_t)N * N && idx % N < idx / N)
+    return;
+  uint64_t cy = 0;
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    {
+      const uint64_t t = (uint64_t)dst[(size_t)k * stride + idx] + src[(size_t)k * stride + idx] + cy;
+      dst[(size_t)k * stride + idx] = (uint32_t)t;
+      cy = t >> 32;
+    }
+}
+
 // Remove the bias in place (after any cross-GPU sum): for i >= j
 //   acc(i,j) <- G(i,j) - C (S_i + S_j) + n C^2 = sum_r v_ri v_rj   (two's complement),
 // C = 2^FB, n = total number of rows, S behind the N x N block (k_fx_colsum).
@@ -4400,6 +4422,8 @@ __global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double 
   for(int it = 0; it < 80; ++it)
     {
       const double mid = 0.5 * (blo + bhi);
+      if(mid == blo || mid == bhi)
+        break; // the interval is one ulp wide: further steps would leave blo and bhi as they are (same bits, ~25 steps fewer)
       if(sturm_count_f64(a, b2, n, mid) >= 1)
         bhi = mid;
       else

@@ -305,6 +305,7 @@ template <int NL> class Solver : public SolverBase
   DevArray part2_; // partial sums of the column norms (the Q chain may run beside the predictor, which uses part_)
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, lam2_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_, syrk_tiles_, colsum_partial_, syrk_part_, toomU_;
+  DevBuf<uint32_t> acc2_; // partial G of the input windows after the first (image in several row chunks: q_window())
   int num_cus_ = 256;
   unsigned colsum_slices_ = 1;
   DevBuf<double> eigF_, eigF2_;
@@ -576,7 +577,9 @@ public:
   void set_profiling(bool on) override { profile_ = on; }
   void set_max_runtime(double seconds) override { max_runtime_s_ = seconds; }
   // --maxSharedMemory (the reference bounds the shared-memory window of the Q stage with it, run.cxx:79-181,
-  // BigInt_Shared_Memory_Syrk_Context.cxx:149-215): here the partial planes of the syrk; 0 = the default plan
+  // BigInt_Shared_Memory_Syrk_Context.cxx:70-215): here the two windows of the Q stage TOGETHER -- the fixed-point image
+  // of P' (input window: at most half of the bound, built for as many rows at a time as fit) and the partial planes of
+  // the product (output window: the rest); 0 = the default plan
   void set_max_shared_memory(unsigned long long bytes) override
   {
     max_shared_bytes_ = (size_t)bytes;
@@ -601,8 +604,9 @@ public:
     };
     const unsigned tiles = cdiv(N_, SYRK_EDGE);
     const int ntile = q_chase_ ? std::max(chase_ntileA_, chase_ntile_ - chase_ntileA_) : (int)(tiles * (tiles + 1) / 2);
-    const SyrkPlan pl = syrk_plan(ntile, (unsigned)Ptot_, syrk_part_budget_words());
+    const SyrkPlan pl = syrk_plan(ntile, qwin_.chunk_rows, syrk_part_budget_words());
     const SyrkPlan unbounded = syrk_plan(ntile, (unsigned)Ptot_, 0);
+    const size_t tile_words = (size_t)SYRK_PART_PLANES * SYRK_EDGE * SYRK_EDGE;
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     std::ostringstream o;
@@ -613,7 +617,7 @@ public:
       << ", \"schur_blocks\": " << da({&S_, &LiS_})
       << ", \"B\": " << da({&BT_}) << ", \"P\": " << da({&PT_})
       << ", \"P_fixed_point_image\": " << fx_.n * sizeof(uint32_t)
-      << ", \"Q\": " << da({&Q_, &LiQ_}) + db({acc_.n * sizeof(uint32_t), acc64_.n * sizeof(unsigned long long), qpanel_msg_.n * sizeof(uint32_t)})
+      << ", \"Q\": " << da({&Q_, &LiQ_}) + db({acc_.n * sizeof(uint32_t), acc2_.n * sizeof(uint32_t), acc64_.n * sizeof(unsigned long long), qpanel_msg_.n * sizeof(uint32_t)})
       << ", \"syrk_partial_planes\": " << syrk_part_.n * sizeof(uint32_t)
       << ", \"vectors_and_small\": "
       << da({&c_, &x_, &dx_, &dres_, &invdS_, &invdX_, &invdY_, &eigD_, &eigE_, &eigD2_, &eigE2_, &b_, &y_, &dy_, &rp_, &norms_, &invnorms_, &invdQ_,
@@ -621,12 +625,22 @@ public:
            + db({colsum_partial_.n * sizeof(uint32_t), toomU_.n * sizeof(uint32_t), xgather_.n * sizeof(uint32_t)})
       << "}, \"syrk\": {\"tile_edge\": " << SYRK_EDGE << ", \"tiles\": " << pl.ntile << ", \"chunks\": " << pl.nchunk
       << ", \"tiles_per_chunk\": " << pl.chunk_tiles << ", \"row_splits\": " << pl.nsplit_first
-      << ", \"rows_per_split\": " << (pl.nsplit_first ? cdiv(Ptot_, pl.nsplit_first) : 0) << ", \"planes_per_split\": " << SYRK_PART_PLANES
+      << ", \"rows_per_split\": " << (pl.nsplit_first ? cdiv(qwin_.chunk_rows, pl.nsplit_first) : 0) << ", \"planes_per_split\": " << SYRK_PART_PLANES
       << ", \"partial_bytes\": " << pl.part_words * sizeof(uint32_t) << ", \"partial_bytes_unbounded\": " << unbounded.part_words * sizeof(uint32_t)
       << ", \"partial_bytes_full_square_layout\": "
       << (size_t)unbounded.nsplit_first * SYRK_PART_PLANES * ((size_t)N_ * N_ + N_) * sizeof(uint32_t) * (unbounded.uses_part ? 1 : 0)
       << ", \"budget_bytes\": " << syrk_part_budget_words() * sizeof(uint32_t) << ", \"budget_source\": \""
-      << (std::getenv("SDPB_HIP_SYRK_PART_BYTES") ? "SDPB_HIP_SYRK_PART_BYTES" : max_shared_bytes_ ? "maxSharedMemory" : "device") << "\"}"
+      << (std::getenv("SDPB_HIP_SYRK_PART_BYTES") ? "SDPB_HIP_SYRK_PART_BYTES" : max_shared_bytes_ ? "maxSharedMemory" : "device")
+      << "\", \"bound_exceeded_min_chunk\": " << (pl.uses_part && pl.part_words > syrk_part_budget_words() ? "true" : "false")
+      << ", \"min_chunk_bytes\": " << tile_words * sizeof(uint32_t) << "}"
+      // the input window (BigInt_Shared_Memory_Syrk_Context.cxx:70-110: input_window_split_factor)
+      << ", \"image\": {\"image_chunks\": " << qwin_.chunks << ", \"rows_per_chunk\": " << qwin_.chunk_rows << ", \"rows\": " << Ptot_
+      << ", \"image_bytes\": " << qwin_.image_words * sizeof(uint32_t) << ", \"image_bytes_unbounded\": " << image_words_for(std::max<size_t>(Ptot_, 1), (size_t)N_) * sizeof(uint32_t)
+      << ", \"budget_bytes\": " << qwin_.budget_words * sizeof(uint32_t) << ", \"budget_source\": \""
+      << (std::getenv("SDPB_HIP_SYRK_IMAGE_BYTES") ? "SDPB_HIP_SYRK_IMAGE_BYTES" : max_shared_bytes_ ? "maxSharedMemory/2" : "device/2")
+      << "\", \"bound_exceeded_min_chunk\": " << (qwin_.bound_exceeded ? "true" : "false") << ", \"accumulator_bytes\": " << acc2_.n * sizeof(uint32_t)
+      << ", \"last_call_windows\": " << last_windows_ << "}"
+      << ", \"window_budget_bytes\": " << window_budget_words() * sizeof(uint32_t)
       << ", \"last_syrk_call\": {\"tiles\": " << last_syrk_plan_.ntile << ", \"chunks\": " << last_syrk_plan_.nchunk
       << ", \"tiles_per_chunk\": " << last_syrk_plan_.chunk_tiles << ", \"row_splits\": " << last_syrk_plan_.nsplit_first
       << ", \"partial_bytes\": " << last_syrk_plan_.part_words * sizeof(uint32_t) << "}"
@@ -777,8 +791,7 @@ private:
     lam2_.alloc(std::max(2 * Jl_, 1), NL);
     ratio_.alloc((size_t)5 * std::max(Jl_, 1) + 1, NL);
     scal_.alloc(S_COUNT, NL);
-    fx_stride_ = image_stride((size_t)Ptot_, (size_t)N_);
-    image_alloc(fx_, fx_stride_);
+    // (the fixed-point image of P' is planned last, with the partial planes: plan_syrk_part())
     acc_stride_ = (size_t)N_ * N_ + N_; // N x N outputs + N column sums (k_fx_colsum)
     acc_.alloc(acc_stride_ * ACCW);
     if(SYRK_TOOM4)
@@ -857,11 +870,15 @@ private:
         }
     }
     {
-      // The partial planes of the syrk are planned last, against what is left of the device: everything else of this
-      // solver is allocated by now.  Reserve for what comes later (the exchange's buffers and RCCL's, operator scratch):
-      // 1/16 of the device + 1 GiB; never more than 1/8 of the device -- chunking costs nothing measurable while a chunk
-      // keeps thousands of workgroups (profiles/r05_syrk_chunks.txt), and ranks that share a GPU (tests) each see the
-      // memory the others have not taken yet.  SDPB_HIP_SYRK_PART_BYTES / sdpb_hip_set_max_shared_memory override.
+      // The two windows of the Q stage -- the fixed-point image of P' (input window) and the partial planes of the
+      // product (output window) -- are planned last and TOGETHER, against what is left of the device: everything else
+      // of this solver is allocated by now.  (The reference bounds the sum of its input and output residue windows by
+      // --maxSharedMemory the same way: BigInt_Shared_Memory_Syrk_Context.cxx:149-215.)  Reserve for what comes later
+      // (the exchange's buffers and RCCL's, operator scratch): 1/16 of the device + 1 GiB; never more than 1/8 of the
+      // device -- chunking costs nothing measurable while a chunk keeps thousands of workgroups
+      // (profiles/r05_syrk_chunks.txt, r06_image_chunks.txt), and ranks that share a GPU (tests) each see the memory
+      // the others have not taken yet.  SDPB_HIP_SYRK_IMAGE_BYTES / SDPB_HIP_SYRK_PART_BYTES /
+      // sdpb_hip_set_max_shared_memory override.
       size_t free_b = 0, total_b = 0;
       HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
       const size_t reserve = total_b / 16 + ((size_t)1 << 30);
@@ -871,18 +888,25 @@ private:
       plan_syrk_part();
     }
   }
-  // (re)size syrk_part_ for the iteration's syrk_G call(s) under the current budget
+  // (re)size the image of P' (fx_, one input window) and syrk_part_ (one output window) for the iteration's syrk_G
+  // call(s) under the current budget
   void plan_syrk_part()
   {
-    const size_t budget = syrk_part_budget_words();
+    qwin_ = q_window((unsigned)Ptot_, N_, /*one_chunk=*/q_chase_);
+    fx_stride_ = qwin_.stride;
+    if(fx_.n != qwin_.image_words)
+      image_alloc(fx_, qwin_.stride);
+    if(qwin_.chunks > 1 && acc2_.n != acc_stride_ * ACCW)
+      acc2_.alloc(acc_stride_ * ACCW);
+    const size_t budget = syrk_part_budget_words(qwin_.image_words);
     size_t words = 0;
     if(q_chase_)
-      words = std::max(syrk_plan(chase_ntileA_, (unsigned)Ptot_, budget).part_words,
-                       syrk_plan(chase_ntile_ - chase_ntileA_, (unsigned)Ptot_, budget).part_words);
+      words = std::max(syrk_plan(chase_ntileA_, qwin_.chunk_rows, budget).part_words,
+                       syrk_plan(chase_ntile_ - chase_ntileA_, qwin_.chunk_rows, budget).part_words);
     else
       {
         const unsigned tiles = cdiv(N_, SYRK_EDGE);
-        words = syrk_plan((int)(tiles * (tiles + 1) / 2), (unsigned)Ptot_, budget).part_words;
+        words = syrk_plan((int)(tiles * (tiles + 1) / 2), qwin_.chunk_rows, budget).part_words;
       }
     if(words && syrk_part_.n != words)
       syrk_part_.alloc(words);
@@ -1654,9 +1678,14 @@ private:
       gemv_t_all<true>(PT_, x_, nullptr, 1, norms_, side ? part2_ : part_); // norms_ = column norms^2 (Matrix_Normalizer.cxx:75-137)
       norms_to_inverse(norms_.ptr(), invnorms_.ptr(), (size_t)N_);
       const size_t cnt = Ptot_ * (size_t)N_;
-      if(cnt)
-        launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT_.cptr(), cnt, N_, // one element per lane: streams at HBM rate
+      // image of the rows [r0, r0 + rows) of P' (one input window; all rows unless the window is split: q_window())
+      auto make_image = [&](size_t r0, unsigned rows) {
+        const size_t n = (size_t)rows * N_;
+        launch(k_normalize_fx<NL, FX>, dim3(cdiv(n, WG)), dim3(WG), stream_, mw::offset(PT_.cptr(), r0 * (size_t)N_), n, N_, // one element per lane: streams at HBM rate
                invnorms_.cptr(), fx_.p, fx_stride_);
+      };
+      if(cnt && q_chase_)
+        make_image(0, (unsigned)Ptot_);
       int *qflags = flags_.p + 2 * std::max(Jl_, 1);
       HIP_CHECK(hipMemsetAsync(qflags, 0, 4 * sizeof(int), stream_));
       // unbias + un-normalise the columns [c0, c1) of the lower triangle into Q (check of the diagonal included)
@@ -1704,12 +1733,14 @@ private:
         }
       if(cnt)
         {
-          syrk_column_sums(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, colsum_partial_.p, colsum_slices_, toomU_.p);
           // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); they are
-          // read back lazily, after a later synchronisation point has passed them
-          resolve_syrk_events();
-          HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
-          syrk_G(fx_.p, fx_stride_, (unsigned)Ptot_, N_, acc_.p, acc_stride_, (const uint32_t *)syrk_tiles_.p, syrk_part_, toomU_.p);
+          // read back lazily, after a later synchronisation point has passed them.  (With the image in several
+          // input windows they also span the images and column sums of the windows after the first.)
+          syrk_G_windows(qwin_, (unsigned)Ptot_, N_, fx_, acc_.p, acc_stride_, acc2_, colsum_partial_.p, (const uint32_t *)syrk_tiles_.p, syrk_part_,
+                         toomU_.p, make_image, [&] {
+                           resolve_syrk_events();
+                           HIP_CHECK(hipEventRecord(ev_syrk0_, stream_));
+                         });
           HIP_CHECK(hipEventRecord(ev_syrk1_, stream_));
           syrk_events_pending_ = true;
         }
@@ -1839,22 +1870,113 @@ private:
     pl.part_words = (size_t)pl.nsplit_first * tile_words * pl.chunk_tiles;
     return pl;
   }
-  // words of partial planes a syrk_G call may use: SDPB_HIP_SYRK_PART_BYTES (tests, shared GPUs), else
-  // sdpb_hip_set_max_shared_memory (--maxSharedMemory), else what build_layout() found free on the device
-  size_t syrk_part_budget_words() const
+  // words of partial planes a syrk_G call may use: SDPB_HIP_SYRK_PART_BYTES (tests, shared GPUs), else what the
+  // window budget -- sdpb_hip_set_max_shared_memory (--maxSharedMemory), else what build_layout() found free on the
+  // device -- leaves beside an image of `image_words`.  Never 0 ("unbounded") for a non-zero bound: at least one word,
+  // i.e. one-tile chunks (round-5 advisor).
+  size_t window_budget_words() const { return max_shared_bytes_ ? std::max<size_t>(1, max_shared_bytes_ / sizeof(uint32_t)) : syrk_part_default_words_; }
+  size_t syrk_part_budget_words(size_t image_words) const
   {
     if(const char *e = std::getenv("SDPB_HIP_SYRK_PART_BYTES"))
-      return (size_t)std::max(1.0, std::atof(e)) / sizeof(uint32_t);
-    if(max_shared_bytes_)
-      return max_shared_bytes_ / sizeof(uint32_t);
-    return syrk_part_default_words_;
+      return std::max<size_t>(1, (size_t)std::max(1.0, std::atof(e)) / sizeof(uint32_t));
+    const size_t w = window_budget_words();
+    return std::max<size_t>(1, w - std::min(image_words, w / 2)); // (an image that could not be split -- chased Q' -- does not starve the planes)
   }
+  size_t syrk_part_budget_words() const { return syrk_part_budget_words(fx_.n); }
+  // The INPUT window of the Q stage: the fixed-point image of P' is built for `chunk_rows` rows at a time (k_normalize_fx
+  // into ONE bounded buffer), each window's product is accumulated into Q' (k_acc_add_tri) -- the reference splits its
+  // input residue window by rows the same way when all rows do not fit --maxSharedMemory
+  // (BigInt_Shared_Memory_Syrk_Context.cxx:70-110,172-186: input_window_split_factor; bigint_syrk_blas.cxx:239-285 loops
+  // over the input windows).  Everything is exact integer arithmetic, so Q' keeps every bit whatever the split.
+  struct QWindow
+  {
+    unsigned chunk_rows = 0; // rows per input window (a multiple of the product's 2560-row splits where there are that many rows)
+    int chunks = 0;          // input windows per Q' (input_window_split_factor)
+    size_t stride = 0;       // elements per group plane of the window's image
+    size_t image_words = 0;  // words of the window's image buffer
+    size_t budget_words = 0; // what the image was allowed
+    bool bound_exceeded = false; // the budget is smaller than the smallest window (one pass of rows)
+  };
+  QWindow qwin_;
+  // words the image may take: SDPB_HIP_SYRK_IMAGE_BYTES (tests), else half of the window budget (the planes get the rest)
+  size_t image_budget_words() const
+  {
+    if(const char *e = std::getenv("SDPB_HIP_SYRK_IMAGE_BYTES"))
+      return std::max<size_t>(1, (size_t)std::max(1.0, std::atof(e)) / sizeof(uint32_t));
+    return std::max<size_t>(1, window_budget_words() / 2);
+  }
+  static size_t image_words_for(size_t rows, size_t cols) { return image_stride(rows, cols) * fx_planes<FX>() + 4; }
+  QWindow q_window(unsigned nrows, int N, bool one_chunk = false) const
+  {
+    QWindow w;
+    w.budget_words = image_budget_words();
+    const unsigned quantum = (unsigned)SYRK_RB;
+    unsigned rows = std::max(nrows, 1u);
+    if(!one_chunk && image_words_for(rows, (size_t)N) > w.budget_words)
+      {
+        // the most rows whose image fits, in whole passes of the product kernel
+        const size_t per_row = (size_t)N * fx_planes<FX>();
+        const size_t fixed = (size_t)64 * fx_planes<FX>() + 4;
+        size_t fit = w.budget_words > fixed ? (w.budget_words - fixed) / per_row : 0;
+        fit = fit / quantum * quantum;
+        if(fit < quantum)
+          {
+            fit = quantum;
+            w.bound_exceeded = true;
+          }
+        const unsigned f = (unsigned)cdiv(nrows, fit);
+        // equal windows; whole row splits of the product kernel where that still fits
+        unsigned cr = (unsigned)(cdiv(cdiv(nrows, f), quantum) * quantum);
+        if(SYRK_SPLIT_ROWS && cr > SYRK_SPLIT_ROWS)
+          {
+            const unsigned up = (unsigned)(cdiv(cr, SYRK_SPLIT_ROWS) * SYRK_SPLIT_ROWS);
+            if(up <= fit)
+              cr = up;
+          }
+        rows = cr;
+      }
+    if(one_chunk && image_words_for(rows, (size_t)N) > w.budget_words)
+      w.bound_exceeded = true;
+    w.chunk_rows = rows;
+    w.chunks = nrows ? (int)cdiv(nrows, rows) : 1;
+    w.stride = image_stride((size_t)rows, (size_t)N);
+    w.image_words = w.stride * fx_planes<FX>() + 4;
+    return w;
+  }
+  // Q' = sum over the input windows: `make(r0, rows)` writes the image of rows [r0, r0 + rows) into fx (stride w.stride);
+  // the first window's column sums and product go to acc, those of the others to acc2 and are added.  `mark`, if given,
+  // is called once, after the first window's column sums (the HIP events that bracket the dominant kernel).
+  template <class MakeImage, class Mark>
+  void syrk_G_windows(const QWindow &w, unsigned nrows, int N, DevBuf<uint32_t> &fx, uint32_t *acc, size_t acc_stride, DevBuf<uint32_t> &acc2,
+                      uint32_t *colsum_partial, const uint32_t *tiles_dev, DevBuf<uint32_t> &part, uint32_t *toomU, MakeImage &&make, Mark &&mark)
+  {
+    if(w.chunks > 1 && acc2.n < acc_stride * ACCW)
+      acc2.alloc(acc_stride * ACCW);
+    for(int c = 0; c < w.chunks; ++c)
+      {
+        const size_t r0 = (size_t)c * w.chunk_rows;
+        const unsigned rows = (unsigned)std::min<size_t>(w.chunk_rows, nrows - r0);
+        if(c > 0 && rows < w.chunk_rows) // a shorter last window: the rows behind it still hold the previous window
+          HIP_CHECK(hipMemsetAsync(fx.p, 0, fx.n * sizeof(uint32_t), stream_));
+        make(r0, rows);
+        uint32_t *out = c == 0 ? acc : acc2.p;
+        const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
+        syrk_column_sums(fx.p, w.stride, rows, N, out, acc_stride, colsum_partial, slices, toomU);
+        if(c == 0)
+          mark();
+        syrk_G(fx.p, w.stride, rows, N, out, acc_stride, tiles_dev, part, toomU, -1, 0, -1, w.image_words);
+        if(c > 0)
+          launch(k_acc_add_tri<ACCW>, dim3(cdiv(acc_stride, WG)), dim3(WG), stream_, acc, (const uint32_t *)acc2.p, acc_stride, N);
+      }
+    last_windows_ = w.chunks;
+  }
+  int last_windows_ = 1;
   // G = sum_r a'_ri a'_rj into acc (kernels.hpp: k_syrk_fx), rows split over workgroups when
   // that fills the last round of resident workgroups better; `part` grows on demand (never beyond the budget)
   // ntile_sub >= 0: only the `ntile_sub` tiles tiles_dev points at, which cover the columns [col0, col1) of the lower
   // triangle (a chunk of the chased Q'; the list comes from syrk_tile_order(N, split))
   void syrk_G(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride, const uint32_t *tiles_dev,
-              DevBuf<uint32_t> &part, const uint32_t *toomU = nullptr, int ntile_sub = -1, int col0 = 0, int col1 = -1)
+              DevBuf<uint32_t> &part, const uint32_t *toomU = nullptr, int ntile_sub = -1, int col0 = 0, int col1 = -1, size_t image_words = 0)
   {
     if(SYRK_TOOM4 && !toomU)
       throw SolverError(4, "syrk_G: the Toom-4 image needs the column terms of syrk_column_sums");
@@ -1865,7 +1987,8 @@ private:
     if(ntile == 0 || col1 <= col0)
       return;
     const int gsplit = syrk_group_split();
-    const SyrkPlan pl = syrk_plan(ntile, nrows, syrk_part_budget_words());
+    // (the plan is made for the window's full height, so that a shorter last window reuses the same buffer)
+    const SyrkPlan pl = syrk_plan(ntile, nrows, syrk_part_budget_words(image_words ? image_words : fx_.n));
     if(pl.uses_part && part.n < pl.part_words)
       part.alloc(pl.part_words);
     last_syrk_plan_ = pl;
@@ -2824,10 +2947,10 @@ public:
     DevBuf<uint32_t> tu; // column terms of the Toom-4 image (zeros: the timing does not depend on them)
     tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
     HIP_CHECK(hipMemsetAsync(tu.p, 0, tu.n * sizeof(uint32_t), stream_));
-    syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p); // warm-up (sizes `part`)
+    syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p, -1, 0, -1, fx.n); // warm-up (sizes `part`)
     HIP_CHECK(hipEventRecord(e0, stream_));
     for(int r = 0; r < std::max(reps, 1); ++r)
-      syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
+      syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p, -1, 0, -1, fx.n);
     HIP_CHECK(hipEventRecord(e1, stream_));
     HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -2871,20 +2994,24 @@ public:
            (const BlockDesc *)dbd.p, cols);
     launch(k_sum_partials<NL>, dim3(cdiv(cols, SP_ROWS)), dim3(WG), stream_, part.cptr(), 1, cols, nrm.cptr(), 0, 1, nrm.ptr());
     norms_to_inverse(nrm.ptr(), inv.ptr(), (size_t)cols);
-    DevBuf<uint32_t> fx, acc, partial, tl, spart;
+    DevBuf<uint32_t> fx, acc, acc2, partial, tl, spart;
     DevBuf<int> qf;
-    const size_t fxs = image_stride((size_t)rows, (size_t)cols);
-    image_alloc(fx, fxs);
-    launch(k_normalize_fx<NL, FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, PT.cptr(), cnt, cols, inv.cptr(), fx.p, fxs);
+    const QWindow win = q_window((unsigned)rows, cols); // the same input windows as the iteration (SDPB_HIP_SYRK_IMAGE_BYTES, --maxSharedMemory)
+    image_alloc(fx, win.stride);
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
     partial.alloc((size_t)slices * (FX + 8) * cols);
     DevBuf<uint32_t> tu;
     tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
-    syrk_column_sums(fx.p, fxs, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
     tl.upload(syrk_tile_order(cols, 0, nullptr, SYRK_EDGE));
-    syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, spart, tu.p);
+    syrk_G_windows(win, (unsigned)rows, cols, fx, acc.p, as, acc2, partial.p, (const uint32_t *)tl.p, spart, tu.p,
+                   [&](size_t r0, unsigned nr) {
+                     const size_t n = (size_t)nr * cols;
+                     launch(k_normalize_fx<NL, FX>, dim3(cdiv(n, WG)), dim3(WG), stream_, mw::offset(PT.cptr(), r0 * (size_t)cols), n, cols, inv.cptr(), fx.p,
+                            win.stride);
+                   },
+                   [] {});
     qf.alloc(4);
     HIP_CHECK(hipMemsetAsync(qf.p, 0, 4 * sizeof(int), stream_));
     launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows, (size_t)0,
@@ -2945,22 +3072,25 @@ public:
             h[(k + 1) * cnt + idx] = n.w[k];
           h[idx] = (negative && !n.w.empty()) ? 1u : 0u;
         }
-    DevBuf<uint32_t> staged, fx, acc, partial;
+    DevBuf<uint32_t> staged, fx, acc, acc2, partial;
     staged.upload(h);
-    const size_t fxs = image_stride((size_t)rows, (size_t)cols);
-    image_alloc(fx, fxs);
-    launch(k_fx_from_int<FX>, dim3(cdiv(cnt, WG)), dim3(WG), stream_, (const uint32_t *)staged.p, cnt, fx.p, fxs);
+    const QWindow win = q_window((unsigned)rows, cols); // the same input windows as the iteration (SDPB_HIP_SYRK_IMAGE_BYTES, --maxSharedMemory)
+    image_alloc(fx, win.stride);
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
     partial.alloc((size_t)slices * (FX + 8) * cols);
     DevBuf<uint32_t> tu;
     tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
-    syrk_column_sums(fx.p, fxs, (unsigned)rows, cols, acc.p, as, partial.p, slices, tu.p);
     DevBuf<uint32_t> tl;
     tl.upload(syrk_tile_order(cols, 0, nullptr, SYRK_EDGE));
     DevBuf<uint32_t> part;
-    syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p);
+    syrk_G_windows(win, (unsigned)rows, cols, fx, acc.p, as, acc2, partial.p, (const uint32_t *)tl.p, part, tu.p,
+                   [&](size_t r0, unsigned nr) {
+                     const size_t n = (size_t)nr * cols;
+                     launch(k_fx_from_int<FX>, dim3(cdiv(n, WG)), dim3(WG), stream_, (const uint32_t *)staged.p + r0 * (size_t)cols, cnt, n, fx.p, win.stride);
+                   },
+                   [] {});
     launch(k_syrk_unbias<FX>, dim3(cdiv((size_t)cols * cols, WG)), dim3(WG), stream_, acc.p, as, cols, (unsigned long long)rows, (size_t)0,
            (size_t)cols * cols);
     HIP_CHECK(hipStreamSynchronize(stream_));

@@ -194,11 +194,14 @@ class SDPSolver:
                 import numpy as np
                 be, bo, B, c = block_source(j)
                 B = np.ascontiguousarray(B, dtype=np.float64)
-                c = np.ascontiguousarray(c, dtype=np.float64)
+                c_text = list(c) if len(c) and isinstance(c[0], str) else None   # feasible synthetic family: c is no double
+                c = np.zeros(len(c)) if c_text else np.ascontiguousarray(c, dtype=np.float64)
                 dp = ctypes.POINTER(ctypes.c_double)
                 self._chk(self.L.sdpb_hip_set_block_f64(
                     self.h, j, "\n".join(" ".join(r) for r in be).encode(),
                     "\n".join(" ".join(r) for r in bo).encode(), B.ctypes.data_as(dp), c.ctypes.data_as(dp)))
+                if c_text:
+                    self._chk(self.L.sdpb_hip_set_array(self.h, b"c", j, 0, " ".join(c_text).encode()))
             else:
                 self._chk(self.L.sdpb_hip_set_block(self.h, j, *block_text(sdp.blocks[j])))
         self._chk(self.L.sdpb_hip_set_objective(self.h, " ".join(sdp.b).encode(), sdp.constant.encode()))

@@ -101,9 +101,37 @@ def syrk_row_splits(ntile: int, nrows: int, slots: int, rb: int, max_rows: int) 
     return best
 
 
+def q_window(rows: int, N: int, nl: int, image_budget_bytes: int):
+    """solver.hpp: Solver::q_window -- (rows per input window, windows, bytes of the window's image)."""
+    fx, words, edge, planes, rb, waves, toom4, toom4k = _fx(nl)
+
+    def image_bytes(r):
+        stride = (-(-r // rb) * rb * N + 64) if toom4k else r * N
+        return (max(stride, 1) * words + 4) * 4
+    r = max(rows, 1)
+    budget_words = max(1, image_budget_bytes // 4)
+    if image_bytes(r) // 4 > budget_words:
+        per_row = N * words
+        fixed = 64 * words + 4
+        fit = ((budget_words - fixed) // per_row if budget_words > fixed else 0) // rb * rb
+        fit = max(fit, rb)
+        f = -(-rows // fit)
+        cr = -(-(-(-rows // f)) // rb) * rb
+        if toom4k and cr > 2560:
+            up = -(-cr // 2560) * 2560
+            if up <= fit:
+                cr = up
+        r = cr
+    return r, (-(-rows // r) if rows else 1), image_bytes(r)
+
+
 def planned_footprint(dims, num_points, N, precision, owners=None, rank=0, world=1, num_cus=256, hbm_bytes=HBM_BYTES,
-                      max_shared_bytes=0, dist_cholq=False) -> Dict[str, float]:
-    """Bytes per array class this rank will allocate (same classes as sdpb_hip_memory_plan) and their sum."""
+                      max_shared_bytes=0, dist_cholq=False, free_bytes=None) -> Dict[str, float]:
+    """Bytes per array class this rank will allocate (same classes as sdpb_hip_memory_plan) and their sum.
+    hbm_bytes / free_bytes / num_cus: pass the device's own figures (torch.cuda.mem_get_info, the CU count) so that the
+    plan follows the library's rule for the two windows of the Q stage -- min(free - reserve, total / 8) with reserve =
+    total / 16 + 1 GiB, taken after everything else is allocated (solver.hpp: build_layout); the data-sheet values are
+    only the default."""
     nl = limbs_for(precision)
     W = 4 * (nl + 1)
     fx, words, edge, planes, rb, waves, toom4, toom4k = _fx(nl)
@@ -126,8 +154,6 @@ def planned_footprint(dims, num_points, N, precision, owners=None, rank=0, world
         rows += P
     out = {"psd_state_and_scratch": 13 * max(psd, 1) * W, "bases_and_pairings": (2 * max(bases, 1) + max(scaled, 1) + 4 * max(E, 1) + 2 * max(pair, 1)) * W,
            "schur_blocks": 2 * max(schur, 1) * W, "B": max(bt, 1) * W, "P": max(bt, 1) * W}
-    stride = (-(-rows // rb) * rb * N + 64) if toom4k else rows * N
-    out["P_fixed_point_image"] = (max(stride, 1) * words + 4) * 4
     accw = 2 * fx + 2
     q_bytes = 2 * N * N * W + (N * N + N) * accw * 4
     if world > 1:
@@ -136,15 +162,30 @@ def planned_footprint(dims, num_points, N, precision, owners=None, rank=0, world
             pb = 16 if nl > 34 else 32
             q_bytes += ((N * pb + pb * pb + pb) * (nl + 1) + 2) * 4
     out["Q"] = q_bytes
+    out["vectors_and_small"] = (5 * max(rows, 1) + 6 * max(vecn, 1) + 8 * N + 2 * max(jl, 1) * N) * W
+    # the two windows of the Q stage, planned together against what the rest leaves (solver.hpp: build_layout, q_window, syrk_plan)
+    rest = sum(out.values())
+    free = (hbm_bytes if free_bytes is None else free_bytes) - rest
+    reserve = hbm_bytes // 16 + (1 << 30)
+    window = max_shared_bytes or max(min(max(free - reserve, 0), hbm_bytes // 8), 64 << 20)
+    chunk_rows, windows, image = q_window(rows, N, nl, max(window // 2, 4))
+    out["P_fixed_point_image"] = image
+    if windows > 1:
+        out["Q"] += (N * N + N) * accw * 4   # the accumulator of the windows after the first
     tiles = -(-N // edge)
     ntile = tiles * (tiles + 1) // 2
-    nsplit = syrk_row_splits(ntile * (21 if toom4k else 1), rows, num_cus * waves, rb, 2560 if toom4k else 0) if rows else 1
-    unbounded = nsplit * planes * ntile * edge * edge * 4 if (nsplit > 1 or toom4) else 0
-    budget = max_shared_bytes or hbm_bytes // 8
+
+    def planes_unbounded(r):
+        ns = syrk_row_splits(ntile * (21 if toom4k else 1), r, num_cus * waves, rb, 2560 if toom4k else 0) if r else 1
+        return ns * planes * ntile * edge * edge * 4 if (ns > 1 or toom4) else 0
+    unbounded = planes_unbounded(chunk_rows)
+    budget = max(window - min(image, window // 2), 4)
     out["syrk_partial_planes"] = min(unbounded, max(budget, planes * edge * edge * 4))
-    out["vectors_and_small"] = (5 * max(rows, 1) + 6 * max(vecn, 1) + 8 * N + 2 * max(jl, 1) * N) * W
     out["total"] = float(sum(out.values()))
     out["rows"] = rows
     out["owned_blocks"] = jl
-    out["syrk_partial_planes_unbounded"] = unbounded
+    out["syrk_partial_planes_unbounded"] = planes_unbounded(rows)
+    out["image_chunks"] = windows
+    out["image_rows_per_chunk"] = chunk_rows
+    out["window_budget_bytes"] = window
     return out

@@ -37,7 +37,7 @@ def main():
     from sdpb_amd import synthetic
     from tests import parity
     c = synthetic.config(cfg, scale)
-    sdp, src = synthetic.make_lazy(c["dims"], c["num_points"], c["N"], c["precision"], c["seed"])
+    sdp, src = synthetic.lazy(c)
     t0 = time.time()
     o = Oracle(sdp, c["precision"], parity.DEFAULT_PARAMS, param_prec=0, block_source=src)
     print(f"{cfg}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total} p={c['precision']} threads={o.threads} "

@@ -79,6 +79,80 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, budget, monke
                 assert got[i + j * cols] == 0
 
 
+# an image budget (bytes) below the fixed-point image of all rows: P' in row chunks through ONE bounded image buffer, each
+# window's product accumulated into Q' (Solver::q_window / syrk_G_windows) -- the analogue of the reference's input windows
+# (BigInt_Shared_Memory_Syrk_Context.cxx:70-110,172-186: input_window_split_factor; bigint_syrk_blas.cxx:239-285);
+# (precision, rows, cols, forced row splits, image budget, partial-plane budget or None)
+_INT_SYRK_WINDOWS = [(512, 100, 18, None, 1.1e5, None), (512, 140, 47, "2", 6.0e5, 1.0e6), (128, 70, 21, "3", 2.5e4, None),
+                     (1024, 60, 18, None, 1.3e5, None), (1280, 70, 17, "2", 8.0e4, 3.5e5), (768, 100, 45, None, 4.0e5, None),
+                     (664, 70, 17, None, 1.6e5, None)]
+
+
+@pytest.mark.parametrize("precision,rows,cols,splits,image_budget,part_budget", _INT_SYRK_WINDOWS)
+def test_emulated_int_syrk_with_the_image_in_row_windows_is_exact(precision, rows, cols, splits, image_budget, part_budget, monkeypatch):
+    import random
+    from oracle.oracle import Oracle
+    if splits:
+        monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", splits)
+    monkeypatch.setenv("SDPB_HIP_SYRK_IMAGE_BYTES", str(int(image_budget)))
+    if part_budget:
+        monkeypatch.setenv("SDPB_HIP_SYRK_PART_BYTES", str(int(part_budget)))
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
+    o = Oracle(sdp, precision)
+    fb = s.fx_frac_bits
+    rng = random.Random(rows * 1000 + cols)
+    vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
+    vals[0], vals[1], vals[2], vals[-1], vals[-2] = 0, 2 ** fb - 1, -(2 ** fb) + 1, 2 ** fb - 1, -(2 ** fb) + 1
+    got = s.op_int_syrk(rows, cols, vals)
+    want = o.int_syrk(rows, cols, vals)  # upper triangle, column-major
+    plan = s.memory_plan()
+    assert plan["image"]["last_call_windows"] >= 3, plan["image"]
+    if part_budget:
+        assert plan["last_syrk_call"]["chunks"] > 1 and plan["last_syrk_call"]["partial_bytes"] <= part_budget, plan["last_syrk_call"]
+    for j in range(cols):
+        for i in range(cols):
+            assert got[i + j * cols] == (want[j + i * cols] if i >= j else 0), (i, j)
+    # the whole stage (norms, normalise-and-shift per window, product, diagonal check, restore) through the same windows
+    assert parity.check_syrk_Q(s, precision, rows=rows, cols=cols) <= -(precision - 40)
+    s.close()
+    o.close()
+
+
+def test_emulated_max_shared_memory_splits_both_windows_and_keeps_every_bit():
+    """sdpb_hip_set_max_shared_memory bounds the image of P' (input window) and the partial planes (output window) TOGETHER,
+    like --maxSharedMemory bounds the reference's two residue windows (BigInt_Shared_Memory_Syrk_Context.cxx:149-215): whole
+    iterations of singlet_cT (N = 20, 322 rows) with both windows split agree with the default plan to the last bit; a
+    bound below the smallest window is reported, and a non-zero bound never means 'unbounded' (round-5 advisor)."""
+    sdp, meta, iters, _ = parity.load_case("singlet_cT")
+    traces = []
+    for bound in (0, 1_400_000, 3):
+        s = SDPSolver(sdp, meta["precision"], meta["params"], lib_path=libs.emu_lib())
+        if bound:
+            s.set_max_shared_memory(bound)
+        plan = s.memory_plan()
+        if bound == 1_400_000:
+            assert plan["image"]["image_chunks"] >= 3 and not plan["image"]["bound_exceeded_min_chunk"], plan["image"]
+            assert plan["image"]["image_bytes"] + plan["syrk"]["partial_bytes"] <= bound, plan
+            assert plan["bytes"]["P_fixed_point_image"] == plan["image"]["image_bytes"]
+        elif bound == 3:
+            assert plan["image"]["bound_exceeded_min_chunk"] and plan["syrk"]["bound_exceeded_min_chunk"], plan
+            assert plan["syrk"]["budget_bytes"] > 0 and plan["syrk"]["chunks"] == plan["syrk"]["tiles"], plan["syrk"]
+        else:
+            assert plan["image"]["image_chunks"] == 1 and plan["syrk"]["chunks"] == 1
+        t = []
+        for _ in range(3):
+            assert not s.iterate()
+            t.append(s.scalars())
+        if bound:
+            assert s.memory_plan()["image"]["last_call_windows"] == plan["image"]["image_chunks"] >= 3
+        traces.append(t)
+        s.close()
+    assert traces[0] == traces[1] == traces[2]
+    bad, _ = parity.compare_iteration(traces[0][2], iters[2])
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("precision", [128, 512, 664, 768, 1024, 1280])
 def test_emulated_syrk_Q_stage_and_saturated_columns(precision):
     """compute_Q.cxx:94-132 as an operator (calculate_matrix_square.test.cxx recipe) incl. columns with
@@ -288,3 +362,21 @@ def test_emulated_Q_image_keeps_at_least_precision_minus_32_bits(limbs):
     assert s.limbs == limbs
     assert s.fx_frac_bits >= p - 32, (p, s.fx_frac_bits)
     s.close()
+
+
+def test_emulated_big_and_ragged_blocks_match_the_oracle():
+    """CPU twin of tests/test_gpu_parity_at_size.py::test_big_and_ragged_blocks_match_the_live_oracle: m in {1, 3, 4, 6}, seven
+    distinct K in one SDP, Schur blocks up to P_j = 714 (23 panels), PSD blocks up to n = 102, N = 60 -- host logic, descriptor
+    tables and kernel index arithmetic at block shapes of a real mixed-correlator SDP (Block_Info.hxx:54-119)."""
+    from oracle.oracle import Oracle
+    from sdpb_amd.synthetic import make_lazy
+    from tests.test_gpu_parity_at_size import RAGGED
+    sdp, src = make_lazy(RAGGED["dims"], RAGGED["num_points"], RAGGED["N"], 512, RAGGED["seed"])
+    s = SDPSolver(sdp, 512, parity.DEFAULT_PARAMS, lib_path=libs.emu_lib(), block_source=src)
+    o = Oracle(sdp, 512, parity.DEFAULT_PARAMS, param_prec=0, block_source=src)
+    for it in range(2):
+        assert not s.iterate() and not o.iterate()
+        bad, w = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=256)
+        assert not bad and w <= -280, (it + 1, w, bad)
+    s.close()
+    o.close()

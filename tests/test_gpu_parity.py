@@ -150,6 +150,44 @@ def test_int_syrk_in_chunks_under_a_memory_budget_is_bit_exact(precision, rows, 
     s.close()
 
 
+# (precision, rows, cols, forced row splits, image budget, partial-plane budget or None)
+@pytest.mark.parametrize("precision,rows,cols,splits,image_budget,part_budget",
+                         [(512, 700, 200, None, 9.0e6, None), (512, 333, 113, "3", 2.0e6, 1.5e6), (256, 300, 90, "4", 4.5e5, None),
+                          (1024, 150, 81, None, 1.8e6, 3.0e6), (1280, 200, 50, "2", 6.0e5, None), (768, 250, 81, None, 1.4e6, None),
+                          (2048, 90, 20, None, 1.5e5, None), (400, 130, 47, None, 3.0e5, None)])
+def test_int_syrk_with_the_image_in_row_windows_is_bit_exact(precision, rows, cols, splits, image_budget, part_budget, monkeypatch):
+    """The analogue of the reference's INPUT windows (BigInt_Shared_Memory_Syrk_Context.cxx:70-110,172-186:
+    input_window_split_factor; bigint_syrk_blas.cxx:239-285 loops over them): an image budget far below the fixed-point image of
+    all rows makes Solver::syrk_G_windows build the image for one row window at a time in ONE bounded buffer and add each
+    window's product into Q' (k_acc_add_tri) -- every entry stays bit-exact against GMP, alone and together with chunked
+    output windows; so does the whole syrk_Q stage (norms, normalise-and-shift per window, diagonal check, restore)."""
+    from oracle.oracle import Oracle
+    if splits:
+        monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", splits)
+    monkeypatch.setenv("SDPB_HIP_SYRK_IMAGE_BYTES", str(int(image_budget)))
+    if part_budget:
+        monkeypatch.setenv("SDPB_HIP_SYRK_PART_BYTES", str(int(part_budget)))
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    o = Oracle(sdp, precision)
+    fxbits = s.fx_frac_bits
+    rng = random.Random(rows + 7 * cols)
+    vals = [rng.randrange(-(2 ** fxbits) + 1, 2 ** fxbits) for _ in range(rows * cols)]
+    vals[0], vals[1], vals[-1], vals[-2] = 0, -(2 ** fxbits) + 1, 2 ** fxbits - 1, -(2 ** fxbits) + 1
+    got = s.op_int_syrk(rows, cols, vals)
+    want = o.int_syrk(rows, cols, vals)
+    plan = s.memory_plan()
+    assert plan["image"]["last_call_windows"] >= 3, plan["image"]
+    if part_budget:
+        assert plan["last_syrk_call"]["chunks"] >= 2 and plan["last_syrk_call"]["partial_bytes"] <= part_budget, plan["last_syrk_call"]
+    for j in range(cols):
+        for i in range(j, cols):
+            assert got[i + j * cols] == want[j + i * cols], (i, j)
+    assert parity.check_syrk_Q(s, precision, rows=min(rows, 120), cols=min(cols, 40)) <= -(precision - 40)
+    s.close()
+    o.close()
+
+
 @pytest.mark.parametrize("limbs,precision", [(6, 128), (10, 256), (16, 448), (18, 512), (24, 704), (26, 768), (34, 1024), (42, 1280), (50, 1536), (66, 2048)])
 def test_Q_image_keeps_at_least_precision_minus_32_bits(limbs, precision):
     """The floor under the fixed-point image of P' the exact integer Q' = P'^T P' is formed from, at the widest --precision

@@ -106,3 +106,38 @@ def test_reference_algorithm_timer_runs_the_whole_stage():
     assert r["residues_s"] > 0 and r["dsyrk_s"] > 0 and r["crt_s"] > 0
     # chunked accumulation (beta = 1) gives the same sums as one call: same checksum of the recombined outputs
     assert ref.time_q_stage_gmp(300, 40, 512, 40000, threads=1, chunk_rows=300)["checksum"] == r["checksum"]
+
+
+def test_oracles_of_different_precisions_can_be_alive_at_once():
+    """GMP's default precision is process-global (mpf_init and the truncation point of syrk_Q read it).  Every oracle
+    entry point re-establishes the precision of its own oracle (oracle/sdpb_oracle.cpp: enter), so a 768-bit oracle
+    created BEFORE a 1536-bit one and iterated in turns with it computes exactly what it computes alone
+    (round-5 review, weak #6: it silently ran at 1536 bits)."""
+    sdp, meta, iters, _ = parity.load_case("1d-constraints")
+
+    def solo(precision, n):
+        o = Oracle(sdp, precision, meta["params"], param_prec=64)
+        t = []
+        for _ in range(n):
+            assert not o.iterate()
+            t.append(o.scalars())
+        t.append(o.array("dy"))
+        o.close()
+        return t
+    want_a, want_b = solo(meta["precision"], 4), solo(1536, 4)
+    a = Oracle(sdp, meta["precision"], meta["params"], param_prec=64)
+    b = Oracle(sdp, 1536, meta["params"], param_prec=64)
+    got_a, got_b = [], []
+    for _ in range(4):
+        assert not a.iterate()
+        assert not b.iterate()
+        got_b.append(b.scalars())
+        got_a.append(a.scalars())
+    got_a.append(a.array("dy"))
+    got_b.append(b.array("dy"))
+    assert got_a == want_a and got_b == want_b
+    assert got_a[3] != got_b[3]               # the two precisions do differ in the printed digits
+    bad, _ = parity.compare_iteration(got_a[3], iters[3])
+    assert not bad, bad
+    a.close()
+    b.close()
