@@ -100,7 +100,9 @@ int sdpb_hip_get_scalar(sdpb_hip_ctx *ctx, const char *name, char *buf, size_t b
  * index (must be owned by this rank), parity 0/1 for block-diagonal members. */
 int sdpb_hip_get_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, char *buf, size_t buflen,
                        size_t *needed);
-/* Inject x, X, y or Y (text checkpoint: load_text_checkpoint.cxx:6-44). */
+/* Inject x, X, y or Y (text checkpoint: load_text_checkpoint.cxx:6-44); dx / dy for sdpb_hip_schur_solve; c = the primal
+ * objective entries of block j (SDP.hxx:84-100) as decimals, for callers that fed B and c as doubles (sdpb_hip_set_block_f64)
+ * although c is no double. */
 int sdpb_hip_set_array(sdpb_hip_ctx *ctx, const char *which, int j, int parity, const char *values);
 
 /* The part of the step that approx_objective and outer_limits reuse

@@ -2772,8 +2772,8 @@ public:
   }
   void set_array_mpf(const std::string &which, int j, int parity, int limbs64, const uint64_t *values, size_t count) override
   {
-    if(which != "x" && which != "X" && which != "y" && which != "Y" && which != "dx" && which != "dy")
-      throw SolverError(4, "set_array: only x, X, y, Y (state) and dx, dy (right-hand sides of schur_solve) can be set");
+    if(which != "x" && which != "X" && which != "y" && which != "Y" && which != "dx" && which != "dy" && which != "c")
+      throw SolverError(4, "set_array: only x, X, y, Y (state), dx, dy (right-hand sides of schur_solve) and c (after set_block_f64) can be set");
     if(which != "y" && which != "dy" && local_index(j) < 0)
       return;
     const ArrayRef r = locate(which, j, parity);
@@ -2784,8 +2784,8 @@ public:
   // checkpoint-style state injection (x, X, y, Y): column-major decimals
   void set_array(const std::string &which, int j, int parity, const char *txt) override
   {
-    if(which != "x" && which != "X" && which != "y" && which != "Y" && which != "dx" && which != "dy")
-      throw SolverError(4, "set_array: only x, X, y, Y (state) and dx, dy (right-hand sides of schur_solve) can be set");
+    if(which != "x" && which != "X" && which != "y" && which != "Y" && which != "dx" && which != "dy" && which != "c")
+      throw SolverError(4, "set_array: only x, X, y, Y (state), dx, dy (right-hand sides of schur_solve) and c (after set_block_f64) can be set");
     if(which != "y" && which != "dy" && local_index(j) < 0)
       return;
     const ArrayRef r = locate(which, j, parity);

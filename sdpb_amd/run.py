@@ -201,7 +201,10 @@ def solve(argv: Optional[List[str]] = None) -> str:
         plan = solver.memory_plan()
         print("Memory plan of this rank (bytes): " + ", ".join(f"{k} {v}" for k, v in plan["bytes"].items())
               + f"; total {sum(plan['bytes'].values())} of {plan['device']['total_bytes']} on the device")
-        print("Q' = P'^T P': " + ", ".join(f"{k} {v}" for k, v in plan["syrk"].items()))
+        # the two windows of the Q stage that --maxSharedMemory bounds together (BigInt_Shared_Memory_Syrk_Context.cxx:70-215)
+        print(f"Q' = P'^T P' windows: window_budget_bytes {plan.get('window_budget_bytes')}; input (image of P'): "
+              + ", ".join(f"{k} {v}" for k, v in plan.get("image", {}).items()))
+        print("Q' = P'^T P' output (partial planes): " + ", ".join(f"{k} {v}" for k, v in plan["syrk"].items()))
     if o.verbosity >= 1:
         print(f"Initialize SDP solver\n\tprimal dimension: {sdp.P_total}\n\tdual dimension: {sdp.N}"
               f"\n\tSDP blocks: {sdp.J}")

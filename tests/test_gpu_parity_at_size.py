@@ -336,7 +336,7 @@ def test_max_shared_memory_bounds_the_syrk_and_keeps_every_bit(monkeypatch):
             assert plan["image"]["image_chunks"] >= 5 and plan["image"]["rows_per_chunk"] % 32 == 0, plan["image"]
             assert plan["image"]["image_bytes"] + plan["syrk"]["partial_bytes"] <= bound, (plan["image"], plan["syrk"])
             assert plan["bytes"]["syrk_partial_planes"] + plan["bytes"]["P_fixed_point_image"] <= bound, plan["bytes"]
-            assert plan["syrk"]["chunks"] >= 2 and not plan["image"]["bound_exceeded_min_chunk"], plan["syrk"]
+            assert not plan["image"]["bound_exceeded_min_chunk"] and not plan["syrk"]["bound_exceeded_min_chunk"], plan
         elif bound_frac:
             bound = plans[0]["syrk"]["partial_bytes"] // bound_frac
             assert plan["syrk"]["budget_source"] == "SDPB_HIP_SYRK_PART_BYTES" and plan["image"]["image_chunks"] == 1
@@ -356,7 +356,7 @@ def test_max_shared_memory_bounds_the_syrk_and_keeps_every_bit(monkeypatch):
         traces.append(t)
         if bound_frac:
             last = s.memory_plan()
-            assert last["last_syrk_call"]["chunks"] >= 2
+            assert last["last_syrk_call"]["chunks"] >= (2 if chase == "1" else 1)
             assert last["image"]["last_call_windows"] == plan["image"]["image_chunks"]
         s.close()
     assert traces[0] == traces[1] == traces[2]

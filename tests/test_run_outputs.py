@@ -103,7 +103,7 @@ def test_max_shared_memory_option_and_memory_plan_of_the_driver(tmp_path, capsys
     assert run.solve(argv)
     text = capsys.readouterr().out
     assert "Memory plan of this rank (bytes): psd_state_and_scratch" in text and "budget_source maxSharedMemory" in text
-    assert f"budget_bytes {int(100.1 * 1024) // 4 * 4}" in text
+    assert f"window_budget_bytes {int(100.1 * 1024) // 4 * 4}" in text and "image_chunks" in text   # both windows under the one bound
     _check_outputs("dfibo", out_dir)
 
 
