@@ -27,6 +27,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LIMB_MAC_PEAK = 19.3e12        # measured on MI355X: v_mad_u64_u32 + v_addc_co_u32 pairs/s at >= 2 wavefronts per SIMD (profiles/r04_ubench_macpairs.txt;
                                # the 17.0e12 of profiles/r01_ubench.txt, used until the last build of round 4, came from a loop of 8 pairs per 19 instructions)
+LIMB_MAD_PEAK = 37.6e12        # measured on MI355X: v_mad_u64_u32 ALONE (the lazy-carry kernels: 28-/27-bit limbs, no v_addc) at 4 wavefronts per SIMD,
+                               # 34.7e12 at 2 (profiles/r06d_ubench_mad_only.txt): 4.2 cycles per instruction and SIMD against 8.2 for the pair
 
 
 def _probe_reference_binary():
@@ -143,7 +145,11 @@ def cpu_baseline(cfg_name: str, precision: int, seconds_budget: float = 45.0, fu
                                             "what": "oracle/bigint_syrk_blas.py + oracle/sdpb_oracle.cpp: Fmpz_Comb primes, centred "
                                                     "residues by mpz_fdiv_ui per prime (OpenMP), one scipy.linalg.blas.dsyrk per prime at "
                                                     "full N accumulated over row chunks, CRT of all N(N+1)/2 outputs by mpz_addmul_ui over "
-                                                    "the primes (OpenMP): the whole stage, crt_included"},
+                                                    "the primes (OpenMP): the whole stage, crt_included",
+                                            # round-5 advisor: the residues and the CRT are the plain per-prime GMP forms; the reference
+                                            # uses FLINT's precomputed remainder / product trees (fmpz_multi_mod, fmpz_multi_CRT_ui),
+                                            # which are cheaper -- FLINT is not in this image, so this leg cannot be calibrated here
+                                            "bound": "UPPER bound on the reference's time for residues and CRT (no FLINT trees); dsyrk is like for like"},
             "value_with_reference_q_stage": 1.0 / t_ref,
             "sample": probe_note + f"`value` = the PORT as measured: oracle (GMP mpf restatement, OpenMP over blocks/columns, "
                       f"{threads} threads on {cores} host cores) on {cfg_name} x{scale}: J={sdp.J}, N={sdp.N}, P_tot={sdp.P_total}; "
@@ -185,6 +191,9 @@ def parity_gate(solver, workload: str, scale: float, precision: int):
     tol_bits = precision // 2
     thr_path = os.path.join(os.path.dirname(path), "gate_thresholds.json")
     early = None          # (n, bits): a tighter bar for the first n iterations (the ones the clock sees), "<fixture>#first<n>"
+    pinned = None         # (measured worst per iteration, margin): "<fixture>#measured_by_iteration" -- every iteration is held to
+                          # what this path was measured at on the device plus a few bits, so that a loss of bits in the LATE
+                          # iterations (where the one floor 2^-(p/2) leaves tens of bits of slack) is noticed too (round-5 advisor)
     if os.path.exists(thr_path):
         with open(thr_path) as f:
             thr = json.load(f)
@@ -192,6 +201,8 @@ def parity_gate(solver, workload: str, scale: float, precision: int):
         for key, bits in thr.items():
             if key.startswith(os.path.basename(path) + "#first"):
                 early = (int(key.split("#first")[1]), int(bits))
+        if os.path.basename(path) + "#measured_by_iteration" in thr:
+            pinned = (thr[os.path.basename(path) + "#measured_by_iteration"], float(thr.get("#drift_margin_bits", 12)))
     worst, bad_all, by_iteration = float("-inf"), [], []
     for rec in fx["iterations"]:
         if solver.iterate():
@@ -202,6 +213,8 @@ def parity_gate(solver, workload: str, scale: float, precision: int):
         by_iteration.append(round(w, 1))
         if early and rec["iteration"] <= early[0] and w > -early[1] and not bad:
             bad_all.append((rec["iteration"], [("worst field of an early iteration", w, -early[1])]))
+        if pinned and rec["iteration"] <= len(pinned[0]) and w > pinned[0][rec["iteration"] - 1] + pinned[1] and not bad:
+            bad_all.append((rec["iteration"], [("drift against the measured trajectory", w, pinned[0][rec["iteration"] - 1] + pinned[1])]))
         if bad:
             bad_all.append((rec["iteration"], bad))
     terminated = None
@@ -221,6 +234,7 @@ def parity_gate(solver, workload: str, scale: float, precision: int):
     return {"fixture": os.path.relpath(path, ROOT), "iterations": len(fx["iterations"]), "tolerance_log2_rel": -tol_bits,
             "worst_log2_rel": worst, "passed": not bad_all, "violations": bad_all[:4], "followed_to_termination": terminated,
             "worst_log2_rel_by_iteration": by_iteration,
+            "pinned_to_measured_trajectory": ({"margin_bits": pinned[1], "iterations": len(pinned[0])} if pinned else None),
             "early_iterations_bar": ({"first": early[0], "tolerance_log2_rel": -early[1],
                                       "worst_log2_rel": max(by_iteration[:early[0]]) if by_iteration else None} if early else None),
             "fields": "mu P-obj D-obj gap P-err p-err D-err R-err P-step D-step beta Q_cond_number max_block_cond_number"}
@@ -650,9 +664,13 @@ def main():
         achieved = k_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         # which instantiation that is: two Karatsuba levels keep 7 spare bits in the image, one level 3
         fb = solver.fx_frac_bits
-        fx = next(f for f in range(solver.limbs - 2, solver.limbs + 1) if 32 * f - fb in (25, 17, 7, 3))   # limbs of the image (kernels.hpp: fx_limbs)
+        lazy = bool(timers1.get("kernel.k_syrk_fx.toom5k_lazy_carries", 0))   # Toom-5 x Karatsuba on 28-bit limbs: multiply-adds without carry instructions
+        mac_peak = LIMB_MAD_PEAK if lazy else LIMB_MAC_PEAK
+        fx = 16 if lazy else next(f for f in range(solver.limbs - 2, solver.limbs + 1) if 32 * f - fb in (25, 17, 7, 3))   # limbs of the image (kernels.hpp: fx_limbs)
         rbg = 16 if fx >= 32 else 32   # rows per pass (solver.hpp: SDPB_SYRK2_RBG)
-        k_name = (f"k_syrk_fx3<{fx},{rbg}> (Toom-4 x Karatsuba, +k_syrk4_finish)" if 32 * fx - 25 == fb else
+        k_name = (f"k_syrk_fx3<{fx},{rbg}> in lazy-carry mode (Toom-5 x Karatsuba on 28-bit limbs: 27 products of 2 x 2 limbs, one v_mad_u64_u32 per "
+                  "limb pair; +k_syrk3_sum_splits +k_syrk5_finish)" if lazy else
+                  f"k_syrk_fx3<{fx},{rbg}> (Toom-4 x Karatsuba, +k_syrk4_finish)" if 32 * fx - 25 == fb else
                   f"k_syrk_fx2<{fx},{rbg},toom4> (+k_syrk4_finish)" if 32 * fx - 17 == fb else
                   f"k_syrk_fx2<{fx},{rbg}> (+k_syrk_reduce)" if 32 * fx - 7 == fb else f"k_syrk_fx<{fx}> (+k_syrk_reduce)")
         traffic, traffic_source = None, None
@@ -714,7 +732,9 @@ def main():
                          "measured_copy_peak": copy_gbs,
                          "launch_ms": 1000.0 * k_avg_s, "algorithmic_bytes_per_launch": k_bytes,
                          "limb_mac_per_s": k_macs / k_avg_s if k_avg_s > 0 else 0.0,
-                         "limb_mac_frac_of_measured_valu_peak": (k_macs / k_avg_s / LIMB_MAC_PEAK) if k_avg_s > 0 else 0.0,
+                         "limb_mac_frac_of_measured_valu_peak": (k_macs / k_avg_s / mac_peak) if k_avg_s > 0 else 0.0,
+                         "measured_valu_peak_limb_mac_per_s": mac_peak,
+                         "valu_peak_is": ("v_mad_u64_u32 alone (lazy carries)" if lazy else "v_mad_u64_u32 + v_addc_co_u32 pairs"),
                          # how the launch was cut (solver.hpp: syrk_plan): output tiles per chunk under the memory bound, row
                          # splits per tile and their length -- above P_tot = 81 920 rows the "<= 2560 rows per split" rule that
                          # keeps the operand panels in L2 stops holding (32 splits at most) and this shows it

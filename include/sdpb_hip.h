@@ -285,6 +285,11 @@ int sdpb_hip_op_int_syrk(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, c
  * column-major (upper part zero), one decimal per line.  Returns 1 with the reference's
  * "Normalized Q should have ones on diagonal" text if the check fails. */
 int sdpb_hip_op_syrk_Q(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, char *buf, size_t buflen, size_t *needed);
+/* min_eigenvalue (step_length/min_eigenvalue.cxx:8-33: El::HermitianEig + El::Min) as an operator: the smallest eigenvalue of
+ * the symmetric n x n matrix A (column-major decimals) through the kernels of the step length (Householder tridiagonalisation,
+ * bisection + Newton on the shifted tridiagonal matrix).  The parity tests aim it at what whole iterations reach only late in a
+ * convergent run: spectra clustered within 2^-k of one value.  Result: one decimal. */
+int sdpb_hip_op_min_eigenvalue(sdpb_hip_ctx *ctx, int n, const char *A, char *buf, size_t buflen, size_t *needed);
 /* Host-side fixed-point exchange image helpers (used by the world_size-2 gloo tests to
  * check the u64-lane reduction without a GPU): encode a two's-complement integer given
  * in decimal into `planes` 32-bit limbs widened to uint64 lanes; decode after a lane-wise

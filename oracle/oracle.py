@@ -58,6 +58,8 @@ def lib():
         L.orc_parse_exact.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.orc_scalar_op.restype = ctypes.c_char_p
         L.orc_scalar_op.argtypes = [ctypes.c_void_p] + [ctypes.c_char_p] * 3
+        L.orc_min_eigenvalue.restype = ctypes.c_char_p
+        L.orc_min_eigenvalue.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p]
         L.orc_get_records.restype = ctypes.c_long
         L.orc_get_records.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_long]
@@ -219,6 +221,10 @@ class Oracle:
 
     def scalar_op(self, op, a, b="0"):
         return self.L.orc_scalar_op(self.h, op.encode(), str(a).encode(), str(b).encode()).decode()
+
+    def min_eigenvalue(self, n, A_colmajor) -> str:
+        """min_eigenvalue.cxx:8-33 on one symmetric matrix (column-major decimals)."""
+        return self.L.orc_min_eigenvalue(self.h, n, " ".join(str(v) for v in A_colmajor).encode()).decode()
 
     def close(self):
         if self.h:

@@ -2016,6 +2016,20 @@ const char *orc_scalar_op(void *h, const char *op, const char *a, const char *b)
   return o->strbuf.c_str();
 }
 
+// min_eigenvalue.cxx:8-33 on one symmetric n x n matrix given column-major (the tests aim clustered spectra at it)
+const char *orc_min_eigenvalue(void *h, int n, const char *txt)
+{
+  Oracle *o = enter(h);
+  std::vector<F> v;
+  parse_list(txt, v, (size_t)n * n, "A");
+  Mat A(n, n);
+  for(int j = 0; j < n; ++j)
+    for(int i = 0; i < n; ++i)
+      A(i, j) = v[(size_t)i + (size_t)j * n];
+  o->strbuf = to_str(min_eigenvalue_sym(A));
+  return o->strbuf.c_str();
+}
+
 // ---------------------------------------------------------------------------
 // Steps 2 and 4 of the reference's OWN algorithm for Q' = P'^T P' on GMP (CPU-baseline leg of bench.py; the
 // description and step 3, one dsyrk per prime, are in oracle/bigint_syrk_blas.py):

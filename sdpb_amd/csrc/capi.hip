@@ -541,6 +541,16 @@ int sdpb_hip_op_syrk_Q(sdpb_hip_ctx *ctx, int rows, int cols, const char *P, cha
   return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
 }
 
+int sdpb_hip_op_min_eigenvalue(sdpb_hip_ctx *ctx, int n, const char *A, char *buf, size_t buflen, size_t *needed)
+{
+  int rc = guarded(ctx, [&] {
+    if(!A)
+      throw sdpb::SolverError(4, "sdpb_hip_op_min_eigenvalue: null argument");
+    ctx->strbuf = ctx->solver->op_min_eigenvalue(n, A);
+  });
+  return rc ? rc : copy_out(ctx, ctx->strbuf, buf, buflen, needed);
+}
+
 int sdpb_hip_host_encode_u64(const char *s, int planes, unsigned long long *lanes)
 {
   if(!s || !lanes || planes <= 0)

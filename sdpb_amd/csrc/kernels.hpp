@@ -13,6 +13,7 @@
 #pragma once
 #include "dev.hpp"
 #include "mw_wave.hpp"
+#include "tiledot.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -914,6 +915,276 @@ template <int NL> __global__ void __launch_bounds__(WG) k_trsm_rlt_panel(Batch L
     }
   trsm_rlt_tile<NL, PB>(L, Li, X, src, dl, di, dx, k0, nb, smem);
 }
+// ---- P = L^{-1} B as fixed-point tile dot products (tiledot.hpp; round 6) ---------------------------------------------
+// Panel p of the solve is  T = X_p - sum_{kt < p} X_kt L(p, kt)^T  followed by  X_p = T Li_pp^T: p + 1 dot products over
+// tiles of PB terms per output.  k_td_image_L rewrites every tile of every block -- the tiles L(panel p, tile kt) below the
+// diagonal and the inverted diagonal blocks Li_pp -- ONCE per factorisation as biased fixed-point images (+ row exponents
+// and limb sums); k_trsm_rlt_panel_td rewrites its own 8 rows of the X tile (and of T) on the fly, one entry per lane, and a
+// term is then W (W+1)/2 + W - 1 multiply-adds (298 at 18 limbs, one v_mad_u64_u32 each at 4.2 cycles:
+// profiles/r06d_ubench_mad_only.txt) against 188 pairs + ~250 instructions for the float term.  Each tile's sum enters the
+// float accumulator as one term.  Panels of <= 16 columns keep the float path (trsm_rlt_tile).
+template <int NL> constexpr bool td_trsm_enabled()
+{
+#if defined(SDPB_NO_TILEDOT)
+  return false;
+#else
+  return PB == 32 && NL <= 18 && td::fits<td::limbs<NL>(), PB>(); // (24 limbs fit the columns but not 128 VGPRs: not tuned)
+#endif
+}
+// tiles of a block with `rows` rows: (p, kt), 0 <= kt < p < panels, numbered p (p - 1) / 2 + kt, then the diagonal tiles
+MW_HD int td_offdiag_tiles(int rows) { const int np = (rows + PB - 1) / PB; return np * (np - 1) / 2; }
+MW_HD int td_tiles_of(int rows) { const int np = (rows + PB - 1) / PB; return np * (np + 1) / 2; }
+constexpr int TD_JW = 64 / (WG / PB); // panel columns per wavefront of k_trsm_rlt_panel_td: a wavefront's lanes share the trip count of the triangular phase
+// image layout: tile-major, then [k][column of the panel][W words]; exponents [tile][column]; limb sums [tile][column][W].
+// Diagonal tiles hold Li(c, k) for k <= c and (biased) zeros above; their limb sums run over k < TD_JW (c / TD_JW + 1), the
+// terms the wavefront of column c executes.
+template <int NL>
+__global__ void __launch_bounds__(WG) k_td_image_L(Batch L, Batch Li, const int *tile_off, uint32_t *img, int32_t *exps, uint32_t *sums)
+{
+  constexpr int W = td::limbs<NL>(), KQ = WG / PB < PB ? WG / PB : PB, KPL = PB / KQ; // KQ lanes share a column, KPL entries each
+  static_assert(PB % KQ == 0 || !td_trsm_enabled<NL>(), "the k range of a tile is dealt to the lanes of a column");
+  const int q = blockIdx.y, t = blockIdx.x;
+  const MatDesc d = L.d[q], di = Li.d[q];
+  if(t >= td_tiles_of(d.rows))
+    return;
+  const int noff = td_offdiag_tiles(d.rows);
+  const bool diag = t >= noff;
+  int p = 1, kt = 0;
+  if(diag)
+    p = kt = t - noff;
+  else
+    {
+      while((p + 1) * p / 2 <= t)
+        ++p;
+      kt = t - p * (p - 1) / 2;
+    }
+  const int row0 = PB * p, k0 = PB * kt;
+  const int c = threadIdx.x % PB, kq = threadIdx.x / PB;
+  const bool ok = row0 + c < d.rows;
+  const int limit = diag ? TD_JW * (c / TD_JW + 1) : PB; // terms whose images enter the limb sum of column c
+  const size_t tile = (size_t)tile_off[q] + t;
+  __shared__ int32_t sE[KQ][PB];
+  __shared__ uint32_t sS[KQ][PB][W];
+  Mw<NL> v[KPL];
+  int32_t e = mw::EZERO;
+#pragma unroll
+  for(int u = 0; u < KPL; ++u)
+    {
+      const int k = kq + KQ * u;
+      v[u] = mw::zero<NL>();
+      if(ok && (!diag || (k <= c && k0 + k < d.rows)))
+        v[u] = diag ? mat_ld<NL>(Li, di, row0 + c, k0 + k) : mat_ld<NL>(L, d, row0 + c, k0 + k);
+      e = v[u].e > e ? v[u].e : e;
+    }
+  sE[kq][c] = e;
+  __syncthreads();
+#pragma unroll
+  for(int u = 0; u < KQ; ++u)
+    e = sE[u][c] > e ? sE[u][c] : e;
+  uint32_t s[W];
+#pragma unroll
+  for(int i = 0; i < W; ++i)
+    s[i] = 0;
+#pragma unroll
+  for(int u = 0; u < KPL; ++u)
+    {
+      const int k = kq + KQ * u;
+      uint32_t b[W];
+      td::to_image<NL, W>(v[u], e == mw::EZERO ? 0 : e, b);
+      uint32_t *o = img + ((tile * PB + (size_t)k) * PB + c) * W;
+#pragma unroll
+      for(int i = 0; i < W; ++i)
+        o[i] = b[i];
+      if(k < limit)
+        {
+#pragma unroll
+          for(int i = 0; i < W; ++i)
+            s[i] += b[i];
+        }
+    }
+#pragma unroll
+  for(int i = 0; i < W; ++i)
+    sS[kq][c][i] = s[i];
+  __syncthreads();
+  if(kq == 0)
+    {
+#pragma unroll 1
+      for(int u = 1; u < KQ; ++u)
+#pragma unroll
+        for(int i = 0; i < W; ++i)
+          s[i] += sS[u][c][i];
+      uint32_t *o = sums + (tile * PB + c) * W;
+#pragma unroll
+      for(int i = 0; i < W; ++i)
+        o[i] = s[i];
+      exps[tile * PB + c] = e;
+    }
+}
+
+#ifndef SDPB_TD_KC
+#define SDPB_TD_KC 4 // k-slices of the right operand's image per LDS pass of the tile dot products
+#endif
+#ifndef SDPB_TD_TRSM_WG_PER_CU
+#define SDPB_TD_TRSM_WG_PER_CU 4 // measured on C4 (profiles/r06b_variants.txt): 2 / 3 / 4 workgroups per CU (208 / 168 / 128 VGPRs) 36.9 / 32.6 / 31.2 ms
+#endif
+// One tile of one output per lane: the ROWS x PB image of the left operand is in sX ([k][row][W]), the KC-slices of the
+// right operand's image are streamed from `tile_img` through sL; `terms` (wavefront-uniform) of them are multiplied.
+template <int NL, int W, int ROWS, int KC>
+MW_HD void td_tile_product(td::Cols<W> &g, const uint32_t *sX, uint32_t *sL, const uint32_t *tile_img, int rl, int j, bool ok, int terms)
+{
+  constexpr int SL_WORDS = KC * PB * W;
+  static_assert(SL_WORDS % 4 == 0, "16-byte moves of a slice");
+  td::cols_zero<W>(g);
+  for(int c = 0; c < PB; c += KC)
+    {
+      {
+        const td::Quad *gsrc = reinterpret_cast<const td::Quad *>(tile_img + (size_t)c * PB * W);
+        td::Quad *dst = reinterpret_cast<td::Quad *>(sL);
+        for(int f = threadIdx.x; f < SL_WORDS / 4; f += WG)
+          dst[f] = gsrc[f];
+      }
+      __syncthreads();
+      if(ok)
+        {
+#pragma unroll 1
+          for(int kk = 0; kk < KC; ++kk)
+            if(c + kk < terms)
+              {
+                uint32_t xb[W], lb[W];
+                const uint32_t *px = sX + ((c + kk) * ROWS + rl) * W, *pl = sL + (kk * PB + j) * W;
+#pragma unroll
+                for(int i = 0; i < W; ++i)
+                  {
+                    xb[i] = px[i];
+                    lb[i] = pl[i];
+                  }
+                td::mac<W>(g, xb, lb);
+              }
+        }
+      __syncthreads();
+    }
+}
+// The workgroup's ROWS x PB tile of numbers -- lane (rl, j) holds entry (rl, j) -- as a fixed-point image in sX, the row
+// exponent in F, the limb sums of the first TD_JW, 2 TD_JW, ... entries of every row in sS ([prefix][row][W]).
+template <int NL, int W, int ROWS>
+MW_HD void td_stage_rows(const Mw<NL> &xv, int rl, int j, uint32_t *sX, int32_t *sExp, uint32_t *sS, int32_t &F)
+{
+  sExp[j * ROWS + rl] = xv.e;
+  __syncthreads(); // (also: the previous tile's reads of sX and sS are over)
+  F = mw::EZERO;
+#pragma unroll 8
+  for(int u = 0; u < PB; ++u)
+    {
+      const int32_t e = sExp[u * ROWS + rl];
+      F = e > F ? e : F;
+    }
+  {
+    uint32_t b[W];
+    td::to_image<NL, W>(xv, F == mw::EZERO ? 0 : F, b);
+    uint32_t *o = sX + (j * ROWS + rl) * W;
+#pragma unroll
+    for(int i = 0; i < W; ++i)
+      o[i] = b[i];
+  }
+  __syncthreads();
+  if(threadIdx.x < ROWS * W) // limb sums of the image rows (not carried: 32 x 2^27 < 2^32)
+    {
+      const int rr = threadIdx.x % ROWS, i = threadIdx.x / ROWS;
+      uint32_t s = 0;
+#pragma unroll 8
+      for(int u = 0; u < PB; ++u)
+        {
+          s += sX[(u * ROWS + rr) * W + i];
+          if((u + 1) % TD_JW == 0)
+            sS[((u / TD_JW) * ROWS + rr) * W + i] = s;
+        }
+    }
+}
+template <int NL>
+__global__ void __launch_bounds__(WG, SDPB_TD_TRSM_WG_PER_CU)
+  k_trsm_rlt_panel_td(Batch L, Batch Li, Batch X, mw::CPtr src, int p, unsigned long long *cyc, const int *tile_off, const uint32_t *img,
+                      const int32_t *exps, const uint32_t *sums)
+{
+  constexpr int KC = SDPB_TD_KC, W = td::limbs<NL>(), ROWS = WG / PB, NPRE = PB / TD_JW;
+  const int q = blockIdx.y;
+  WgClock clk(cyc, q);
+  const MatDesc dl = L.d[q], di = Li.d[q], dx = X.d[q];
+  const int k0 = PB * p;
+  if(k0 >= dl.rows)
+    return;
+  const int nb = dl.rows - k0 < PB ? dl.rows - k0 : PB;
+  // LDS: the float path's tiles (narrow panels) and, over the same bytes, the fixed-point tiles
+  constexpr int FLOAT_WORDS = (NL + 2) * (WG + PB * TRSM_KC);
+  constexpr int SX_WORDS = PB * ROWS * W, SL_WORDS = KC * PB * W;
+  constexpr int TD_WORDS = SX_WORDS + SL_WORDS + PB * ROWS + NPRE * ROWS * W;
+  __shared__ __attribute__((aligned(16))) uint32_t smem[FLOAT_WORDS > TD_WORDS ? FLOAT_WORDS : TD_WORDS];
+  if constexpr(PB >= 32)
+    {
+      if(nb <= 8)
+        return trsm_rlt_tile<NL, 8>(L, Li, X, src, dl, di, dx, k0, nb, smem);
+      if(nb <= 16)
+        return trsm_rlt_tile<NL, 16>(L, Li, X, src, dl, di, dx, k0, nb, smem);
+    }
+  if((int)(blockIdx.x * ROWS) >= dx.rows)
+    return;
+  uint32_t *sL = smem, *sX = smem + SL_WORDS;          // (sL first: its 16-byte moves want the aligned base)
+  int32_t *sExp = (int32_t *)(sX + SX_WORDS);           // [k][row]
+  uint32_t *sS = (uint32_t *)(sExp + PB * ROWS);        // [prefix][row][W]
+  const int rl = threadIdx.x % ROWS, j = threadIdx.x / ROWS;
+  const int r0 = blockIdx.x * ROWS, r = r0 + rl;
+  const bool ok = r < dx.rows && j < nb;
+  mw::Acc<NL> acc = mw::acc_zero<NL>();
+  if(ok)
+    mw::acc_add(acc, mw::load<NL>(src, (size_t)dx.off + (size_t)r + (size_t)(k0 + j) * dx.ld));
+  const size_t tbase = (size_t)tile_off[q], tile0 = tbase + (size_t)p * (p - 1) / 2;
+  for(int kt = 0; kt < p; ++kt)
+    {
+      // T -= X(rows, tile kt) L(panel p, tile kt)^T
+      const Mw<NL> xv = r < dx.rows ? mat_ld<NL>(X, dx, r, PB * kt + j) : mw::zero<NL>();
+      int32_t F;
+      td_stage_rows<NL, W, ROWS>(xv, rl, j, sX, sExp, sS, F);
+      td::Cols<W> g;
+      td_tile_product<NL, W, ROWS, KC>(g, sX, sL, img + (tile0 + kt) * (size_t)PB * PB * W, rl, j, ok, PB);
+      if(ok)
+        {
+          uint32_t sx[W], sl[W];
+          const uint32_t *ps = sums + ((tile0 + kt) * PB + j) * W;
+#pragma unroll
+          for(int i = 0; i < W; ++i)
+            {
+              sx[i] = sS[((NPRE - 1) * ROWS + rl) * W + i];
+              sl[i] = ps[i];
+            }
+          td::acc_add_tile<NL, W>(acc, g, sx, sl, (uint32_t)PB, F, exps[(tile0 + kt) * PB + j], 1u);
+        }
+    }
+  // X(r, k0 + j) = sum_{j2 <= j} T(r, j2) Li(k0 + j, k0 + j2): the diagonal tile; the wavefront of columns [TD_JW w, TD_JW (w+1))
+  // multiplies the first TD_JW (w + 1) terms (the entries above the diagonal are zeros of the image: they cancel exactly)
+  {
+    const Mw<NL> tv = ok ? mw::acc_result(acc) : mw::zero<NL>();
+    const int pre = j / TD_JW, terms = TD_JW * (pre + 1);
+    const size_t dtile = tbase + td_offdiag_tiles(dl.rows) + p;
+    int32_t F;
+    td_stage_rows<NL, W, ROWS>(tv, rl, j, sX, sExp, sS, F);
+    td::Cols<W> g;
+    td_tile_product<NL, W, ROWS, KC>(g, sX, sL, img + dtile * (size_t)PB * PB * W, rl, j, ok, terms);
+    if(ok)
+      {
+        uint32_t sx[W], sl[W];
+        const uint32_t *ps = sums + (dtile * PB + j) * W;
+#pragma unroll
+        for(int i = 0; i < W; ++i)
+          {
+            sx[i] = sS[(pre * ROWS + rl) * W + i];
+            sl[i] = ps[i];
+          }
+        acc = mw::acc_zero<NL>();
+        td::acc_add_tile<NL, W>(acc, g, sx, sl, (uint32_t)terms, F, exps[dtile * PB + j], 0u);
+        mat_st<NL>(X, dx, r, k0 + j, mw::acc_result(acc));
+      }
+  }
+}
+
 // X := X L^{-1}, panel p (backward over panels):
 //   T = X(:,panel p) - X(:,cols >= k0+nb) L(rows >= k0+nb, panel p) ;  X(:,panel p) = T Li_pp
 // The mirror image of trsm_rlt_tile: the same workgroup tile, the same limb-major LDS staging of
@@ -1907,13 +2178,43 @@ template <int FX> constexpr bool fx_toom4k()
   return fx_toom4<FX>() && (FX == 16 || FX == 24 || FX == 32); // M3 = 2, 3, 4 limbs per piece (above, the 4 x (2 M3 - 1) x 3 accumulator registers of a lane no longer fit)
 #endif
 }
-// bits per Toom-4 piece
-template <int FX> constexpr int toom_wb() { return 32 * (FX / 4) - (fx_toom4k<FX>() ? 6 : 4); }
+// TOOM-5 x KARATSUBA WITH LAZY CARRIES (fx_toom5k<FX>(): FX = 16, i.e. --precision 400 ... 512; round 6).  v_mad_u64_u32 alone
+// issues every 4.2 cycles, the pair with v_addc_co_u32 that a 96-bit column accumulator needs every 8.2
+// (profiles/r06d_ubench_mad_only.txt) -- and the carry instruction is only there because a product of two 32-bit limbs fills
+// 64 bits.  With 28-bit limbs a limb product is < 2^56 and a column of a 2 x 2-limb product can absorb 64 rows before it
+// is carried: the row loop is multiply-adds and nothing else.  To keep the image wide with narrower pieces the row
+// polynomial gets FIVE pieces instead of four: a' = a0 + a1 b + ... + a4 b^4, pieces of w = 102 bits, evaluated at the nine
+// points 0, 1, -1, 2, -2, 1/2, -1/2, 3, inf (every value < 121 b < 2^109; the three signed points stored with a bias
+// K = 2 b, 10 b, 10 b that the column sums remove exactly, as in Toom-4), each evaluated value split once more
+// (Karatsuba: halves of H = 55 bits and their sum, < 2^56 = two 28-bit limbs): 27 products of 2 x 2 limbs per row pair =
+// 108 multiply-adds of ONE instruction each, against the 84 pairs = 168 instructions of Toom-4 x Karatsuba -- and
+// FB = 5 w - 1 = 509 fraction bits, where Toom-4 x Karatsuba keeps 487 and the reference 512.  The interpolation (a 9 x 9
+// integer matrix with exact divisions, derived in profiles/tools/toom5_matrix.py) runs once per output element in
+// k_syrk5_finish.  Image: 27 pieces of two words (limbs < 2^28), group 3 g + u, g the point, u in (lo, hi, mid).
+template <int FX> constexpr bool fx_toom5k()
+{
+#if defined(SDPB_SYRK_NO_TOOM5K)
+  return false;
+#else
+  return fx_toom4k<FX>() && FX == 16;
+#endif
+}
+constexpr int T5_LB = 28;                         // bits per limb of a Toom-5 half-piece
+constexpr uint32_t T5_MASK = (1u << T5_LB) - 1u;
+constexpr int T5_H = 55;                          // bits per half of an evaluated piece
+// products per row pair, limbs of one product's sum over a row split
+template <int FX> constexpr int fx_nprod() { return fx_toom5k<FX>() ? 27 : 21; }
+template <int FX> constexpr int fx_part_limbs() { return fx_toom5k<FX>() ? 5 : 2 * (FX / 8) + 1; } // (2^112 per row, < 2^32 rows)
+// bits per Toom piece
+template <int FX> constexpr int toom_wb() { return fx_toom5k<FX>() ? 102 : 32 * (FX / 4) - (fx_toom4k<FX>() ? 6 : 4); }
 template <int FX> constexpr int fx_planes()
 {
-  return fx_toom4k<FX>() ? 21 * (FX / 8) : fx_toom4<FX>() ? 7 * (FX / 4) : fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2);
+  return fx_toom5k<FX>() ? 27 * 2 : fx_toom4k<FX>() ? 21 * (FX / 8) : fx_toom4<FX>() ? 7 * (FX / 4) : fx_two_level<FX>() ? 9 * (FX / 4) : 3 * (FX / 2);
 }
-template <int FX> constexpr int fx_frac_bits() { return fx_toom4<FX>() ? 4 * toom_wb<FX>() - 1 : fx_two_level<FX>() ? 32 * FX - 7 : 32 * FX - 3; }
+template <int FX> constexpr int fx_frac_bits()
+{
+  return fx_toom5k<FX>() ? 5 * toom_wb<FX>() - 1 : fx_toom4<FX>() ? 4 * toom_wb<FX>() - 1 : fx_two_level<FX>() ? 32 * FX - 7 : 32 * FX - 3;
+}
 // elements per group plane of the image of a rows x cols operand: k_syrk_fx3 stages whole blocks of `rb` rows and
 // whole 32-column tiles without bounds checks, so its image is padded (the pad is zeroed once, when the image is allocated)
 template <int FX> constexpr size_t fx_image_stride(size_t rows, size_t cols, int rb)
@@ -1969,11 +2270,17 @@ template <int W, int A> MW_HD void add_shifted(uint32_t (&w)[W], const uint32_t 
 // write the 3M planes of one element from sign + FX-limb magnitude (|v| < 2^FB)
 template <int FX> MW_HD void fx_store2(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx);
 template <int FX> MW_HD void fx_store4(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx);
+template <int FX> MW_HD void fx_store5(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx);
 template <int FX> MW_HD void fx_store(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
 {
   constexpr int M = FX / 2;
   static_assert(FX % 2 == 0 && FX >= 4, "FX = NL - 2 is even");
-  if constexpr(fx_toom4<FX>())
+  if constexpr(fx_toom5k<FX>())
+    {
+      fx_store5<FX>(mag, negative, fx, fx_stride, idx);
+      return;
+    }
+  else if constexpr(fx_toom4<FX>())
     {
       fx_store4<FX>(mag, negative, fx, fx_stride, idx);
       return;
@@ -2155,6 +2462,108 @@ template <int A> MW_HD void sub_limbs(uint32_t (&d)[A], const uint32_t (&x)[A])
       const uint64_t t = (uint64_t)d[k] - (uint64_t)x[k] - bw;
       d[k] = (uint32_t)t;
       bw = (t >> 63) & 1u;
+    }
+}
+
+// ---- Toom-5 x Karatsuba image (fx_toom5k) ---------------------------------------------------------------------------
+// out = sum_k c_k p_k for small non-negative c_k (< 2^7: no overflow of the ML-limb result by construction)
+template <int ML> MW_HD void toom5_lin(uint32_t (&out)[ML], const uint32_t (&p)[5][ML], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4)
+{
+  uint64_t cy = 0;
+#pragma unroll
+  for(int i = 0; i < ML; ++i)
+    {
+      const uint64_t t = (uint64_t)p[0][i] * c0 + (uint64_t)p[1][i] * c1 + (uint64_t)p[2][i] * c2 + (uint64_t)p[3][i] * c3 + (uint64_t)p[4][i] * c4 + cy;
+      out[i] = (uint32_t)t;
+      cy = t >> 32;
+    }
+}
+// bits [POS, POS + NB) of x (NB <= 32, compile-time position)
+template <int POS, int NB, int ML> MW_HD uint32_t toom5_bits(const uint32_t (&x)[ML])
+{
+  constexpr int q = POS / 32, r = POS % 32;
+  const uint32_t lo = q < ML ? x[q < ML ? q : 0] : 0u, hi = q + 1 < ML ? x[q + 1 < ML ? q + 1 : 0] : 0u;
+  const uint32_t v = r ? ((lo >> r) | (hi << (32 - r))) : lo;
+  return NB < 32 ? (v & ((1u << (NB < 32 ? NB : 0)) - 1u)) : v;
+}
+// The points' order in the image: 0: a0, 1: p(1), 2: p(-1) + 2 b, 3: p(2), 4: p(-2) + 10 b, 5: 16 p(1/2), 6: 16 p(-1/2) + 10 b, 7: p(3), 8: a4
+template <int FX> MW_HD void fx_store5(const uint32_t (&mag)[FX], bool negative, uint32_t *fx, size_t fx_stride, size_t idx)
+{
+  constexpr int WB = toom_wb<FX>(), FB = fx_frac_bits<FX>(), ML = (WB + 7 + 31) / 32, H = T5_H, LB = T5_LB;
+  constexpr int TOPBIT = WB - 32 * (ML - 1); // bit of b = 2^WB inside the top limb of an evaluated piece
+  static_assert(FB == 5 * WB - 1 && FB / 32 == FX - 1, "a' = v + 2^FB fills five pieces of WB bits");
+  static_assert(TOPBIT >= 0 && TOPBIT + 7 <= 32 && WB + 7 <= 2 * H && H + 1 <= 2 * LB, "121 b fits, the halves fit two limbs");
+  uint32_t a[FX];
+  uint64_t borrow = 0;
+#pragma unroll
+  for(int i = 0; i < FX; ++i)
+    {
+      const uint32_t c = (i == FX - 1) ? (1u << (FB % 32)) : 0u;
+      if(negative)
+        {
+          const uint64_t d = (uint64_t)c - (uint64_t)mag[i] - borrow;
+          a[i] = (uint32_t)d;
+          borrow = (d >> 63) & 1u;
+        }
+      else
+        a[i] = mag[i] | c;
+    }
+  uint32_t p[5][ML];
+  bits_slice<0, WB>(a, p[0]);
+  bits_slice<WB, WB>(a, p[1]);
+  bits_slice<2 * WB, WB>(a, p[2]);
+  bits_slice<3 * WB, WB>(a, p[3]);
+  bits_slice<4 * WB, WB>(a, p[4]);
+  uint32_t e[9][ML];
+#pragma unroll
+  for(int i = 0; i < ML; ++i)
+    {
+      e[0][i] = p[0][i];
+      e[8][i] = p[4][i];
+    }
+  toom5_lin<ML>(e[1], p, 1, 1, 1, 1, 1);
+  toom5_lin<ML>(e[3], p, 1, 2, 4, 8, 16);
+  toom5_lin<ML>(e[5], p, 16, 8, 4, 2, 1);
+  toom5_lin<ML>(e[7], p, 1, 3, 9, 27, 81);
+  {
+    // the signed points: positive part (+ bias) minus negative part, never below zero
+    uint32_t pos[ML], neg[ML];
+    auto diff = [&](uint32_t (&out)[ML], uint32_t bias) {
+      pos[ML - 1] += bias << TOPBIT;
+      uint64_t bw = 0;
+#pragma unroll
+      for(int i = 0; i < ML; ++i)
+        {
+          const uint64_t t = (uint64_t)pos[i] - (uint64_t)neg[i] - bw;
+          out[i] = (uint32_t)t;
+          bw = (t >> 63) & 1u;
+        }
+    };
+    toom5_lin<ML>(pos, p, 1, 0, 1, 0, 1);
+    toom5_lin<ML>(neg, p, 0, 1, 0, 1, 0);
+    diff(e[2], 2u); // p(-1) + 2 b
+    toom5_lin<ML>(pos, p, 1, 0, 4, 0, 16);
+    toom5_lin<ML>(neg, p, 0, 2, 0, 8, 0);
+    diff(e[4], 10u); // p(-2) + 10 b
+    toom5_lin<ML>(pos, p, 16, 0, 4, 0, 1);
+    toom5_lin<ML>(neg, p, 0, 8, 0, 2, 0);
+    diff(e[6], 10u); // 16 p(-1/2) + 10 b
+  }
+#pragma unroll
+  for(int g = 0; g < 9; ++g)
+    {
+      // halves of H bits as two limbs of LB bits each, and their sum
+      uint32_t lo[2], hi[2], mid[2];
+      lo[0] = toom5_bits<0, LB>(e[g]);
+      lo[1] = toom5_bits<LB, H - LB>(e[g]);
+      hi[0] = toom5_bits<H, LB>(e[g]);
+      hi[1] = toom5_bits<H + LB, H - LB>(e[g]);
+      const uint32_t s0 = lo[0] + hi[0];
+      mid[0] = s0 & T5_MASK;
+      mid[1] = lo[1] + hi[1] + (s0 >> LB);
+      piece_store<2>(fx + ((size_t)(3 * g + 0) * fx_stride + idx) * 2, lo);
+      piece_store<2>(fx + ((size_t)(3 * g + 1) * fx_stride + idx) * 2, hi);
+      piece_store<2>(fx + ((size_t)(3 * g + 2) * fx_stride + idx) * 2, mid);
     }
 }
 
@@ -3551,8 +3960,11 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
 {
   // gsplit = 7 (21): a workgroup takes the three products of ONE Toom-4 group (one product) of its (tile, row split)
   // instead of all 21 (the sweeps are independent): more workgroups where the output has few tiles, a shorter tail everywhere
-  constexpr int M3 = FX / 8, A3 = 2 * M3 + 1;
-  static_assert(M3 >= 2 && M3 <= 4, "accumulators of 2 x 2 outputs in registers");
+  // LAZY (fx_toom5k: 27 products of pieces with 28-bit limbs): the column accumulators are plain 64-bit sums -- a multiply-add
+  // per limb pair and no carry instruction; they are carried into each other every second pass (64 rows)
+  constexpr bool LAZY = fx_toom5k<FX>();
+  constexpr int M3 = FX / 8, A3 = fx_part_limbs<FX>(), NPROD = fx_nprod<FX>();
+  static_assert(M3 >= 2 && M3 <= 4 && (!LAZY || (M3 == 2 && RBG <= 32)), "accumulators of 2 x 2 outputs in registers; 2 x 32 rows between carries");
   // a staged row = the M3-limb pieces of the tile's 32 columns = ROWW words = UPR 16-byte units (a unit is two pieces at
   // M3 = 2, one at 4, and straddles pieces at 3: the row is contiguous in the image and in LDS either way)
   constexpr int ROWW = 32 * M3, UPR = ROWW / 4, NPAIR = RBG * UPR, GL = NPAIR / WG; // units per operand per pass, per lane
@@ -3574,10 +3986,10 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
     return;
   // items that follow each other share the rows and the group, i.e. the operand panels of neighbouring tiles
   const int sg = item / ntile, tile = item % ntile, split = sg / gsplit;
-  const int prod_begin = (sg % gsplit) * (21 / gsplit), prod_end = prod_begin + 21 / gsplit;
+  const int prod_begin = (sg % gsplit) * (NPROD / gsplit), prod_end = prod_begin + NPROD / gsplit;
   const unsigned row_begin = (unsigned)split * rows_per_split;
   const unsigned row_end = (row_begin + rows_per_split < nrows && split + 1 < nsplit) ? row_begin + rows_per_split : nrows;
-  acc += (size_t)split * 21 * A3 * acc_stride;
+  acc += (size_t)split * NPROD * A3 * acc_stride;
   const uint32_t tt = tile_list[tile];
   const int ti = (int)(tt >> 16), tj = (int)(tt & 0xffffu);
   const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
@@ -3590,6 +4002,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NPAIR * 4 + 64];
   uint64_t cc[4][2 * M3 - 1];
   uint32_t hh[4][2 * M3 - 1];
+  uint64_t c3[4]; // LAZY: what the top column has been carried out of
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK2_NO_GLDS)
   constexpr bool DIRECT = true;
 #else
@@ -3667,7 +4080,15 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
     const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(sa + buf * NPAIR * 4 + li * M3);
     const uint32_t lb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(sb + buf * NPAIR * 4 + lj * M3);
 #define FX3_P(C, H, X, Y) "v_mad_u64_u32 %" #C ", vcc, %" #X ", %" #Y ", %" #C "\n\tv_addc_co_u32 %" #H ", vcc, 0, %" #H ", vcc\n\t"
+#define FX3_L(C, X, Y) "v_mad_u64_u32 %" #C ", vcc, %" #X ", %" #Y ", %" #C "\n\t"
 #define FX3_MAC_BOTH(o0, o1, a0x, a0y, a1x, a1y, bx, by)                                                                                   \
+  if constexpr(LAZY)                                                                                                                       \
+    asm volatile(FX3_L(0, 6, 10) FX3_L(3, 8, 10) FX3_L(1, 6, 11) FX3_L(4, 8, 11) FX3_L(1, 7, 10) FX3_L(4, 9, 10) FX3_L(2, 7, 11)           \
+                   FX3_L(5, 9, 11)                                                                                                         \
+                 : "+v"(c[o0][0]), "+v"(c[o0][1]), "+v"(c[o0][2]), "+v"(c[o1][0]), "+v"(c[o1][1]), "+v"(c[o1][2])                          \
+                 : "v"(a0x), "v"(a0y), "v"(a1x), "v"(a1y), "v"(bx), "v"(by)                                                                \
+                 : "vcc");                                                                                                                 \
+  else                                                                                                                                     \
   asm volatile(FX3_P(0, 6, 12, 16) FX3_P(3, 9, 14, 16) FX3_P(1, 7, 12, 17) FX3_P(4, 10, 14, 17) FX3_P(1, 7, 13, 16) FX3_P(4, 10, 15, 16)   \
                  FX3_P(2, 8, 13, 17) FX3_P(5, 11, 15, 17)                                                                                  \
                : "+v"(c[o0][0]), "+v"(c[o0][1]), "+v"(c[o0][2]), "+v"(c[o1][0]), "+v"(c[o1][1]), "+v"(c[o1][2]), "+v"(h[o0][0]),           \
@@ -3675,6 +4096,12 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
                : "v"(a0x), "v"(a0y), "v"(a1x), "v"(a1y), "v"(bx), "v"(by)                                                                  \
                : "vcc")
 #define FX3_MAC_ONE(o0, ax, ay, bx, by)                                                                                                    \
+  if constexpr(LAZY)                                                                                                                       \
+    asm volatile(FX3_L(0, 3, 5) FX3_L(1, 3, 6) FX3_L(1, 4, 5) FX3_L(2, 4, 6)                                                               \
+                 : "+v"(c[o0][0]), "+v"(c[o0][1]), "+v"(c[o0][2])                                                                          \
+                 : "v"(ax), "v"(ay), "v"(bx), "v"(by)                                                                                      \
+                 : "vcc");                                                                                                                 \
+  else                                                                                                                                     \
   asm volatile(FX3_P(0, 3, 6, 8) FX3_P(1, 4, 6, 9) FX3_P(1, 4, 7, 8) FX3_P(2, 5, 7, 9)                                                     \
                : "+v"(c[o0][0]), "+v"(c[o0][1]), "+v"(c[o0][2]), "+v"(h[o0][0]), "+v"(h[o0][1]), "+v"(h[o0][2])                            \
                : "v"(ax), "v"(ay), "v"(bx), "v"(by)                                                                                        \
@@ -3772,6 +4199,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
 #undef FX3_MAC_ONE
 #undef FX3_MAC_BOTH
 #undef FX3_P
+#undef FX3_L
 #endif
       }
     else
@@ -3788,6 +4216,23 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
               piece_load<M3>(pa + rr * ROWW + 16 * M3, a1);
             if constexpr((MASK & 12) != 0)
               piece_load<M3>(pb + rr * ROWW + 16 * M3, b1);
+            if constexpr(LAZY)
+              {
+                auto lazy = [&](const uint32_t (&x)[M3], const uint32_t (&y)[M3], uint64_t (&cs)[2 * M3 - 1]) {
+                  cs[0] += (uint64_t)x[0] * y[0];
+                  cs[1] += (uint64_t)x[0] * y[1] + (uint64_t)x[1] * y[0];
+                  cs[2] += (uint64_t)x[1] * y[1];
+                };
+                lazy(a0, b0, c[0]);
+                if constexpr((MASK & 2) != 0)
+                  lazy(a1, b0, c[1]);
+                if constexpr((MASK & 4) != 0)
+                  lazy(a0, b1, c[2]);
+                if constexpr((MASK & 8) != 0)
+                  lazy(a1, b1, c[3]);
+              }
+            else
+              {
             SyrkColumns<M3, 0>::run(a0, b0, c[0], h[0]);
             if constexpr((MASK & 2) != 0)
               SyrkColumns<M3, 0>::run(a1, b0, c[1], h[1]);
@@ -3795,6 +4240,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
               SyrkColumns<M3, 0>::run(a0, b1, c[2], h[2]);
             if constexpr((MASK & 8) != 0)
               SyrkColumns<M3, 0>::run(a1, b1, c[3], h[3]);
+              }
           }
       }
   };
@@ -3811,6 +4257,26 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
             cc[o][k] = 0;
             hh[o][k] = 0;
           }
+#pragma unroll
+      for(int o = 0; o < 4; ++o)
+        c3[o] = 0;
+      // LAZY: column k of an output absorbs products < 2^56 (two of them per row in the middle column): after 64 rows it
+      // is < 2^63 and is carried into the next one, the top column into c3
+      auto carry_columns = [&]() __attribute__((always_inline)) {
+        if constexpr(LAZY)
+          {
+#pragma unroll
+            for(int o = 0; o < 4; ++o)
+              {
+                cc[o][1] += cc[o][0] >> T5_LB;
+                cc[o][0] &= T5_MASK;
+                cc[o][2] += cc[o][1] >> T5_LB;
+                cc[o][1] &= T5_MASK;
+                c3[o] += cc[o][2] >> T5_LB;
+                cc[o][2] &= T5_MASK;
+              }
+          }
+      };
       if(prod > prod_begin)
         __syncthreads(); // every wavefront has left the last pass of the previous sweep
       fetch(prod, row_begin, 0);
@@ -3825,10 +4291,13 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
             // (after the last block of the sweep: a block that exists, staged and never read)
             fetch(prod, r0 + RBG < row_end ? r0 + RBG : row_begin, buf ^ 1);
             rows(mask_c, buf, cc, hh);
+            if(LAZY && buf == 1) // every second pass
+              carry_columns();
             store(buf ^ 1);
             __syncthreads();
             buf ^= 1;
           }
+        carry_columns();
       };
       switch(mask)
         {
@@ -3847,6 +4316,18 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
 #pragma unroll
           for(int k = 0; k < A3; ++k)
             g[k] = 0;
+          if constexpr(LAZY)
+            {
+              // c0 + c1 2^28 + c2 2^56 + c3 2^84 with c0, c1, c2 < 2^28 (carried) and c3 < 2^44: 4 words
+              const uint64_t t0 = cc[o][0] + (cc[o][1] << T5_LB);
+              const uint64_t t1 = (t0 >> 32) + (cc[o][2] << (2 * T5_LB - 32));
+              const uint64_t t2 = (t1 >> 32) + (c3[o] << (3 * T5_LB - 64));
+              g[0] = (uint32_t)t0;
+              g[1] = (uint32_t)t1;
+              g[2] = (uint32_t)t2;
+              g[3] = (uint32_t)(t2 >> 32);
+            }
+          else
           syrk_fold<M3, A3>(g, cc[o], hh[o]);
           const size_t at = (size_t)tile * 1024 + (size_t)(li + 16 * (o & 1)) + (size_t)(lj + 16 * (o >> 1)) * 32; // tile-packed
 #pragma unroll
@@ -3864,7 +4345,7 @@ template <int FX>
 __global__ void __launch_bounds__(WG) k_syrk3_sum_splits(uint32_t *part, int nsplit, size_t part_stride, const uint32_t *tile_list, size_t total, int N,
                                                          int col0, int col1)
 {
-  constexpr int M3 = FX / 8, A3 = 2 * M3 + 1;
+  constexpr int A3 = fx_part_limbs<FX>(), NPROD = fx_nprod<FX>(); // (grid.y = NPROD)
   const size_t pidx = (size_t)blockIdx.x * WG + threadIdx.x;
   const int prod = blockIdx.y;
   int i, j;
@@ -3877,13 +4358,316 @@ __global__ void __launch_bounds__(WG) k_syrk3_sum_splits(uint32_t *part, int nsp
     {
 #pragma unroll 8
       for(int s = 0; s < nsplit; ++s)
-        cy += part[(((size_t)s * 21 + prod) * A3 + k) * part_stride + pidx];
+        cy += part[(((size_t)s * NPROD + prod) * A3 + k) * part_stride + pidx];
       out[k] = (uint32_t)cy;
       cy >>= 32;
     }
 #pragma unroll
   for(int k = 0; k < A3; ++k)
     part[((size_t)prod * A3 + k) * part_stride + pidx] = out[k];
+}
+
+// ---- Toom-5 x Karatsuba: column sums and the finishing kernel (fx_toom5k) --------------------------------------------
+// inverse of an odd constant modulo 2^32 (Newton)
+constexpr uint32_t inv_mod_2_32(uint32_t c)
+{
+  uint32_t x = c; // correct to 3 bits
+  for(int i = 0; i < 5; ++i)
+    x *= 2u - c * x;
+  return x;
+}
+constexpr int T5_Z = 10; // limbs of the signed integers of the interpolation
+// the evaluated value lo + hi 2^55 of a point from its two stored halves (limbs of 28 bits), as four 32-bit words
+MW_HD void toom5_value(const uint32_t *fx, size_t fx_stride, int point, size_t e, uint32_t (&w)[4])
+{
+  const PiecePair lo = *reinterpret_cast<const PiecePair *>(fx + ((size_t)(3 * point + 0) * fx_stride + e) * 2);
+  const PiecePair hi = *reinterpret_cast<const PiecePair *>(fx + ((size_t)(3 * point + 1) * fx_stride + e) * 2);
+  w[0] = lo.w[0] | (lo.w[1] << 28);
+  w[1] = (lo.w[1] >> 4) | (hi.w[0] << 23);
+  w[2] = (hi.w[0] >> 9) | (hi.w[1] << 19);
+  w[3] = hi.w[1] >> 13;
+}
+// Stage 1 (the shape of k_fx_colsum2): workgroup (x, y) sums row slice y of 64 columns of the five groups a0, p(1), p(2),
+// 16 p(1/2), a4 -- enough to recover the column sums of all five pieces -- into partial[y]; element (slice, u, k, n), u < 5,
+// k < 5 at ((slice * 5 + u) * 5 + k) * N + n.
+template <int FX>
+__global__ void __launch_bounds__(WG) k_fx_colsum5(const uint32_t *fx, size_t fx_stride, unsigned nrows, int N, unsigned rows_per_slice, uint32_t *partial)
+{
+  constexpr int A = 5, G = 5;
+  const int lane = threadIdx.x & 63, col = blockIdx.x * 64 + lane, phase = threadIdx.x >> 6;
+  const unsigned r_begin = blockIdx.y * rows_per_slice, r_end = (r_begin + rows_per_slice < nrows) ? r_begin + rows_per_slice : nrows;
+  uint32_t sum[G][A];
+#pragma unroll
+  for(int u = 0; u < G; ++u)
+#pragma unroll
+    for(int k = 0; k < A; ++k)
+      sum[u][k] = 0;
+  if(col < N)
+    for(unsigned r = r_begin + phase; r < r_end; r += 4)
+      {
+        const size_t e = (size_t)r * N + col;
+#pragma unroll
+        for(int u = 0; u < G; ++u)
+          {
+            const int point = u == 0 ? 0 : u == 1 ? 1 : u == 2 ? 3 : u == 3 ? 5 : 8;
+            uint32_t src[4];
+            toom5_value(fx, fx_stride, point, e, src);
+            uint64_t cy = 0;
+#pragma unroll
+            for(int k = 0; k < A; ++k)
+              {
+                const uint64_t t = (uint64_t)sum[u][k] + (k < 4 ? src[k < 4 ? k : 0] : 0u) + cy;
+                sum[u][k] = (uint32_t)t;
+                cy = t >> 32;
+              }
+          }
+      }
+  __shared__ uint32_t sm[3 * G * A * 64];
+  if(phase > 0)
+    {
+#pragma unroll
+      for(int u = 0; u < G; ++u)
+#pragma unroll
+        for(int k = 0; k < A; ++k)
+          sm[(((phase - 1) * G + u) * A + k) * 64 + lane] = sum[u][k];
+    }
+  __syncthreads();
+  if(phase == 0 && col < N)
+    {
+      for(int p = 0; p < 3; ++p)
+#pragma unroll
+        for(int u = 0; u < G; ++u)
+          {
+            uint64_t cy = 0;
+#pragma unroll
+            for(int k = 0; k < A; ++k)
+              {
+                const uint64_t t = (uint64_t)sum[u][k] + sm[((p * G + u) * A + k) * 64 + lane] + cy;
+                sum[u][k] = (uint32_t)t;
+                cy = t >> 32;
+              }
+          }
+#pragma unroll
+      for(int u = 0; u < G; ++u)
+#pragma unroll
+        for(int k = 0; k < A; ++k)
+          partial[(((size_t)blockIdx.y * G + u) * A + k) * N + col] = sum[u][k];
+    }
+}
+// Stage 2: the column sums s_0 .. s_4 of the five pieces from the five group sums; S_n = sum_k s_k b^k behind the N x N block
+// of acc; the bias terms of the three signed points, U = K E + n K^2 / 2 with E the column sum of the point's UNBIASED values:
+//   toomU[(t Z + k) N + n], t = 0: p(-1) (K = 2 b), 1: p(-2) (K = 10 b), 2: 16 p(-1/2) (K = 10 b).
+template <int FX>
+__global__ void __launch_bounds__(WG)
+  k_fx_colsum5_final(const uint32_t *partial, int nslices, int N, uint32_t *acc, size_t acc_stride, uint32_t *toomU, unsigned long long nrows_local)
+{
+  constexpr int A = 5, G = 5, W = 2 * FX + 2, WB = toom_wb<FX>(), Z = T5_Z;
+  const int col = blockIdx.x * WG + threadIdx.x;
+  if(col >= N)
+    return;
+  uint32_t g[G][Z];
+#pragma unroll
+  for(int u = 0; u < G; ++u)
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      g[u][k] = 0;
+  for(int sl = 0; sl < nslices; ++sl)
+#pragma unroll
+    for(int u = 0; u < G; ++u)
+      {
+        uint64_t cy = 0;
+#pragma unroll
+        for(int k = 0; k < A + 1; ++k)
+          {
+            const uint64_t t = (uint64_t)g[u][k] + (k < A ? partial[(((size_t)sl * G + u) * A + (k < A ? k : 0)) * N + col] : 0u) + cy;
+            g[u][k] = (uint32_t)t;
+            cy = t >> 32;
+          }
+      }
+  // g: 0 = s0, 1 = p(1), 2 = p(2), 3 = 16 p(1/2), 4 = s4
+  uint32_t s[5][Z], u[Z], v[Z], t[Z];
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      s[0][k] = g[0][k];
+      s[4][k] = g[4][k];
+      u[k] = g[1][k];
+      v[k] = g[2][k];
+      t[k] = g[3][k];
+    }
+  z_sub<Z>(u, s[0]);
+  z_sub<Z>(u, s[4]);                  // u = s1 + s2 + s3
+  z_sub<Z>(v, s[0]);
+  z_addmul<Z>(v, s[4], 16, true);     // v = 2 s1 + 4 s2 + 8 s3
+  z_addmul<Z>(t, s[0], 16, true);
+  z_sub<Z>(t, s[4]);                  // t = 8 s1 + 4 s2 + 2 s3
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    s[2][k] = 0;
+  z_addmul<Z>(s[2], u, 10, false);
+  z_sub<Z>(s[2], v);
+  z_sub<Z>(s[2], t);
+  z_sar<Z>(s[2], 1);                  // s2 = (10 u - v - t) / 2
+  z_sub<Z>(v, t);
+  z_sar<Z>(v, 1);
+  z_divexact<Z>(v, 3u, inv_mod_2_32(3u)); // d = (v - t) / 6 = s3 - s1
+  z_sub<Z>(u, s[2]);                  // u = s1 + s3
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    {
+      s[3][k] = u[k];
+      s[1][k] = u[k];
+    }
+  z_add<Z>(s[3], v);
+  z_sar<Z>(s[3], 1);
+  z_sub<Z>(s[1], v);
+  z_sar<Z>(s[1], 1);
+  {
+    uint32_t w[W];
+#pragma unroll
+    for(int k = 0; k < W; ++k)
+      w[k] = k < Z ? s[0][k < Z ? k : 0] : 0u;
+#pragma unroll
+    for(int q = 1; q < 5; ++q)
+      add_shifted<W, Z>(w, s[q], q * WB, false);
+#pragma unroll
+    for(int k = 0; k < W; ++k)
+      acc[(size_t)k * acc_stride + (size_t)N * N + col] = w[k];
+  }
+  uint32_t n[Z];
+#pragma unroll
+  for(int k = 0; k < Z; ++k)
+    n[k] = k == 0 ? (uint32_t)nrows_local : k == 1 ? (uint32_t)(nrows_local >> 32) : 0u;
+  auto emit = [&](int which, uint32_t c0, bool n0, uint32_t c1, bool n1, uint32_t c2, bool n2, uint32_t c3, bool n3, uint32_t c4, bool n4, bool ten) {
+    uint32_t e[Z], m[Z];
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      e[k] = m[k] = 0;
+    z_addmul<Z>(e, s[0], c0, n0);
+    z_addmul<Z>(e, s[1], c1, n1);
+    z_addmul<Z>(e, s[2], c2, n2);
+    z_addmul<Z>(e, s[3], c3, n3);
+    z_addmul<Z>(e, s[4], c4, n4);
+    if(ten)
+      {
+        // U = 10 b E + 50 n b^2
+#pragma unroll
+        for(int k = 0; k < Z; ++k)
+          t[k] = 0;
+        z_addmul<Z>(t, e, 10, false);
+        z_shl<Z>(t, WB);
+        z_addmul<Z>(m, n, 50, false);
+        z_shl<Z>(m, 2 * WB);
+      }
+    else
+      {
+        // U = 2 b E + 2 n b^2
+#pragma unroll
+        for(int k = 0; k < Z; ++k)
+          {
+            t[k] = e[k];
+            m[k] = n[k];
+          }
+        z_shl<Z>(t, WB + 1);
+        z_shl<Z>(m, 2 * WB + 1);
+      }
+    z_add<Z>(t, m);
+#pragma unroll
+    for(int k = 0; k < Z; ++k)
+      toomU[(size_t)(which * Z + k) * N + col] = t[k];
+  };
+  emit(0, 1, false, 1, true, 1, false, 1, true, 1, false, false);   // E = s0 - s1 + s2 - s3 + s4
+  emit(1, 1, false, 2, true, 4, false, 8, true, 16, false, true);   // E = s0 - 2 s1 + 4 s2 - 8 s3 + 16 s4
+  emit(2, 16, false, 8, true, 4, false, 2, true, 1, false, true);   // E = 16 s0 - 8 s1 + 4 s2 - 2 s3 + s4
+}
+// acc(i,j) (i >= j) = G(i,j) = sum_r a'_ri a'_rj from the 27 product sums k_syrk_fx3 (lazy mode) left in part: add the
+// splits, recombine the three products of a point (e e' = lo lo' + (mid mid' - lo lo' - hi hi') 2^H + hi hi' 2^(2H)), remove
+// the bias of the three signed points, interpolate (c = M V / D row by row, exact divisions), recombine G = sum c_k b^k.
+template <int FX>
+__global__ void __launch_bounds__(WG)
+  k_syrk5_finish(const uint32_t *part, int nsplit, size_t part_stride, const uint32_t *tile_list, size_t total, const uint32_t *toomU,
+                 uint32_t *acc, size_t acc_stride, int N, int col0, int col1)
+{
+  constexpr int A3 = fx_part_limbs<FX>(), Z = T5_Z, W = 2 * FX + 2, WB = toom_wb<FX>(), H = T5_H;
+  const size_t pidx = (size_t)blockIdx.x * WG + threadIdx.x;
+  int i, j;
+  if(pidx >= total || !syrk_packed_decode<syrk_tile_edge<FX>()>(pidx, tile_list, N, col0, col1, i, j))
+    return;
+  const size_t idx = (size_t)i + (size_t)j * N;
+  uint32_t V[9][Z];
+#pragma unroll
+  for(int q = 0; q < 9; ++q)
+    {
+      uint32_t g3[3][A3 + 1];
+#pragma unroll
+      for(int u = 0; u < 3; ++u)
+        {
+          uint64_t cy = 0;
+#pragma unroll
+          for(int k = 0; k < A3; ++k)
+            {
+              for(int sp = 0; sp < nsplit; ++sp)
+                cy += part[(((size_t)sp * 27 + 3 * q + u) * A3 + k) * part_stride + pidx];
+              g3[u][k] = (uint32_t)cy;
+              cy >>= 32;
+            }
+          g3[u][A3] = (uint32_t)cy;
+        }
+      sub_limbs<A3 + 1>(g3[2], g3[0]);
+      sub_limbs<A3 + 1>(g3[2], g3[1]);
+#pragma unroll
+      for(int k = 0; k < Z; ++k)
+        V[q][k] = k < A3 + 1 ? g3[0][k < A3 + 1 ? k : 0] : 0u;
+      add_shifted<Z, A3 + 1>(V[q], g3[2], H, false);
+      add_shifted<Z, A3 + 1>(V[q], g3[1], 2 * H, false);
+    }
+  {
+    uint32_t u[Z];
+#pragma unroll
+    for(int t = 0; t < 3; ++t)
+      {
+        const int q = 2 + 2 * t; // points 2, 4, 6
+#pragma unroll
+        for(int k = 0; k < Z; ++k)
+          u[k] = toomU[(size_t)(t * Z + k) * N + i];
+        z_sub<Z>(V[q], u);
+#pragma unroll
+        for(int k = 0; k < Z; ++k)
+          u[k] = toomU[(size_t)(t * Z + k) * N + j];
+        z_sub<Z>(V[q], u);
+      }
+  }
+  // rows 1 .. 7 of the inverse of the evaluation matrix (points 0, 1, -1, 2, -2, 1/2, -1/2, 3, inf; the halves scaled by 2^8),
+  // each over its common denominator D = 2^SH * ODD (profiles/tools/toom5_matrix.py)
+  constexpr int MI[7][9] = {{-700, -700, 350, 35, -7, 14, -10, -2, 6300},      {-1890, -80, -80, 1, 1, 4, 4, 0, -360},
+                            {3150, 2750, -1175, -155, 29, -23, 5, 9, -28350},  {378, 68, 68, -1, -1, -1, -1, 0, 378},
+                            {-3150, -1450, -125, 145, -19, 13, 5, -9, 28350},  {-360, -80, -80, 4, 4, 1, 1, 0, -1890},
+                            {2100, 700, 350, -70, -14, -7, -5, 6, -18900}};
+  constexpr int SH[7] = {2, 3, 3, 3, 3, 3, 2};
+  constexpr uint32_t ODD[7] = {525, 45, 225, 9, 225, 45, 1575};
+  uint32_t gg[W];
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    gg[k] = k < Z ? V[0][k < Z ? k : 0] : 0u;
+#pragma unroll
+  for(int r = 0; r < 7; ++r)
+    {
+      uint32_t c[Z];
+#pragma unroll
+      for(int k = 0; k < Z; ++k)
+        c[k] = 0;
+#pragma unroll
+      for(int q = 0; q < 9; ++q)
+        if(MI[r][q] != 0)
+          z_addmul<Z>(c, V[q], (uint32_t)(MI[r][q] < 0 ? -MI[r][q] : MI[r][q]), MI[r][q] < 0);
+      z_sar<Z>(c, SH[r]);
+      z_divexact<Z>(c, ODD[r], inv_mod_2_32(ODD[r]));
+      add_shifted<W, Z>(gg, c, (r + 1) * WB, false);
+    }
+  add_shifted<W, Z>(gg, V[8], 8 * WB, false);
+#pragma unroll
+  for(int k = 0; k < W; ++k)
+    acc[(size_t)k * acc_stride + idx] = gg[k];
 }
 
 template <int FX> constexpr int syrk_waves_per_simd() { return fx_toom4k<FX>() ? SDPB_SYRK3_WAVES : SDPB_SYRK_WAVES; }
@@ -4235,10 +5019,26 @@ __global__ void __launch_bounds__(T, T <= 256 ? SDPB_TRI_WAVES : 1024 / T) k_tri
 #endif
 template <int WL, int NL>
 __device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t oe, int n, Mw<WL> &x, double span, int emax,
-                               int backoff_bits)
+                               int backoff_bits, bool &clustered)
 {
+  // clustered (in/out): a narrower rung of the ladder met slow convergence -- then a first step that is already small says
+  // nothing about the distance to go (it is that distance over m), and the rung iterates until two steps show the ratio
   const Mw<WL> minus_one = mw::from_i32<WL>(-1);
   Mw<WL> prev = x;
+  // A CLUSTER of m eigenvalues at the bottom of the spectrum, tighter than the distance still to go, makes the Newton step
+  // 1/m of that distance: linear convergence with ratio 1 - 1/m (round 6: half of the spectrum within 2^-70 of lambda_min kept
+  // the iteration at 2^-73 when its cap of 100 steps ran out).  Two consecutive steps give the ratio and with it the
+  // multiplicity the iteration SEES from where it stands: a step of `mul` Newton steps towards a root of multiplicity M shrinks
+  // the next step by 1 - mul / M.  The step M delta undershoots the cluster only by the second-order term (quadratic
+  // convergence towards the cluster); a multiplicity that was overestimated -- the cluster has a width, and from nearer by
+  // fewer of its eigenvalues count -- shows as a non-positive minor at the next evaluation: the step is taken again from the
+  // same point with three quarters of the multiplier, and that cap stays (what the iteration sees only decreases on the way).
+  // All thresholds are relative to the larger of |x| and the scale of the matrix (2^emax): after the shift of k_tridiag_min
+  // lambda_min can be tiny against the entries, and the noise of the minors is relative to the entries.
+  Mw<WL> pd = mw::zero<WL>(), base = x, base_delta = mw::zero<WL>();
+  bool have_pd = false;
+  int pmul = 1, mul = 1, mcap = n; // multiplier of the previous step, of the step under test, and the cap
+  bool accel_pending = false;
   for(int it = 0; it < 100; ++it)
     {
       Mw<WL> S = mw::zero<WL>(), inv = mw::zero<WL>(), tq = mw::zero<WL>();
@@ -4293,6 +5093,25 @@ __device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t
           S = mw::add(S, tq);
         }
 #endif
+#ifdef SDPB_TRACE_TRIMIN
+      if(overshoot)
+        printf("WL=%d it=%d overshoot accel_pending=%d x.e=%d\n", WL, it, (int)accel_pending, x.e);
+#endif
+      if(overshoot && accel_pending)
+        {
+          // the multiplicity was overestimated: again from the same point with a smaller multiplier (1: the plain Newton step,
+          // which cannot cross the root)
+          mcap = mul - (mul / 4 > 1 ? mul / 4 : 1);
+          mul = mcap;
+          accel_pending = mul >= 2;
+          x = mw::add(base, mul >= 2 ? mw::mul(base_delta, mw::from_u32<WL>((uint32_t)mul)) : base_delta);
+          prev = base;
+          pd = base_delta;
+          pmul = mul;
+          have_pd = true;
+          continue;
+        }
+      accel_pending = false;
       if(overshoot)
         {
           // Newton from below never crosses the root in exact arithmetic: a non-positive
@@ -4305,21 +5124,61 @@ __device__ void tridiag_newton(const Batch &D, const Batch &E, size_t od, size_t
             }
           // the start was not below the spectrum: retreat, 256x further on every retry
           Mw<WL> back = mw::abs(x);
-          if(mw::is_zero(back))
+          if(mw::is_zero(back) || back.e < emax)
             back = mw::mul_2exp(mw::from_double<WL>(span), emax);
           back.e -= backoff_bits - 8 * it;
           x = mw::sub(x, back);
           prev = x;
+          have_pd = false;
           continue;
         }
       if(mw::is_zero(S))
         return;
       const Mw<WL> delta = mw::neg(mw::rcp(S));
+      // ratio of this step to the previous one: ~ 0 while the convergence is quadratic, 1 - pmul / M before a cluster of M
+      double ratio = 0.0;
+      if(have_pd && !mw::is_zero(pd) && !mw::is_zero(delta) && delta.e - pd.e > -60)
+        {
+          ratio = mw::to_double(mw::mul_2exp(delta, -delta.e)) / mw::to_double(mw::mul_2exp(pd, -pd.e));
+          const int de = delta.e - pd.e;
+          for(int k = 0; k < (de < 0 ? -de : de); ++k)
+            ratio *= de < 0 ? 0.5 : 2.0;
+        }
+      // the multiplicity seen from here
+      int m = 1;
+      if(have_pd)
+        {
+          const double est = (double)pmul / (1.0 - (ratio < 0.999 ? ratio : 0.999));
+          m = est >= (double)n ? n : (int)(est + 0.5);
+          m = m > mcap ? mcap : m;
+          m = m < 1 ? 1 : m;
+        }
+      const bool slow = ratio > 0.25 || (clustered && !have_pd);
+      if(ratio > 0.25)
+        clustered = true;
       prev = x;
-      x = mw::add(x, delta);
-      // quadratic convergence: a step below 2^-(16WL+8) |x| leaves an error ~ step^2
-      if(mw::is_zero(delta) || mw::is_zero(x) || delta.e < x.e - (16 * WL + 8))
-        return;
+      const Mw<WL> step = m >= 2 ? mw::mul(delta, mw::from_u32<WL>((uint32_t)m)) : delta;
+      const Mw<WL> xn = mw::add(x, step);
+      const int ref = xn.e > emax ? xn.e : emax;
+#ifdef SDPB_TRACE_TRIMIN
+      printf("WL=%d it=%d x.e=%d delta.e=%d ref=%d ratio=%g m=%d mcap=%d slow=%d clustered=%d have_pd=%d\n", WL, it, x.e, delta.e, ref, ratio, m, mcap,
+             (int)slow, (int)clustered, (int)have_pd);
+#endif
+      // quadratic convergence: a step below 2^-(16WL+8) of the scale leaves an error ~ step^2; while the steps still shrink
+      // slowly only a step below the resolution of the mantissa ends the iteration
+      if(mw::is_zero(step) || mw::is_zero(xn) || step.e < ref - (32 * WL - 6) || (!slow && step.e < ref - (16 * WL + 8)))
+        {
+          x = xn;
+          return;
+        }
+      base = x;
+      base_delta = delta;
+      mul = m;
+      accel_pending = m >= 2;
+      x = xn;
+      pd = delta;
+      pmul = m;
+      have_pd = true;
     }
 }
 
@@ -4333,18 +5192,21 @@ template <int WL, int NL> struct TridiagLadder
 {
   static constexpr int H = WL / 2 + 1;
   static constexpr int MINW = NL / 2 + 1 < 6 ? NL / 2 + 1 : 6;
-  static __device__ void run(const Batch &D, const Batch &E, size_t od, size_t oe, int n, const Mw<NL> &start, Mw<WL> &x, double span, int emax)
+  static __device__ void run(const Batch &D, const Batch &E, size_t od, size_t oe, int n, const Mw<NL> &start, Mw<WL> &x, double span, int emax,
+                             bool &clustered)
   {
     if constexpr(H >= MINW && H < WL)
       {
         Mw<H> xs;
-        TridiagLadder<H, NL>::run(D, E, od, oe, n, start, xs, span, emax);
+        TridiagLadder<H, NL>::run(D, E, od, oe, n, start, xs, span, emax, clustered);
         // step a few ulps of the narrower rung down so that this one starts from below
         Mw<H> ulps = mw::abs(xs);
+        if(mw::is_zero(ulps) || ulps.e < emax)
+          ulps = mw::mul_2exp(mw::from_u32<H>(1), emax); // the noise of a rung is relative to the entries of the matrix
         ulps.e -= 32 * H - 8;
         xs = mw::sub(xs, ulps);
         x = mw::widen<WL, H>(xs);
-        tridiag_newton<WL, NL>(D, E, od, oe, n, x, span, emax, 32 * H - 16);
+        tridiag_newton<WL, NL>(D, E, od, oe, n, x, span, emax, 32 * H - 16, clustered);
       }
     else
       {
@@ -4352,7 +5214,7 @@ template <int WL, int NL> struct TridiagLadder
           x = mw::narrow<WL, NL>(start);
         else
           x = start;
-        tridiag_newton<WL, NL>(D, E, od, oe, n, x, span, emax, 24);
+        tridiag_newton<WL, NL>(D, E, od, oe, n, x, span, emax, 24, clustered);
       }
   }
 };
@@ -4380,6 +5242,16 @@ __global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double 
       return;
     }
   double *a = fa + od, *b2 = fb2 + od;
+  // Shift by the first diagonal entry: lambda_min(T) = c + lambda_min(T - c I).  Near the end of a convergent run every
+  // eigenvalue of L^-1 dX L^-T sits within 2^-40 of -(1 - beta) (step.cxx:202-206: both step lengths come out as
+  // gamma / (1 - beta)): against the spectrum of T the Newton iteration on det(T - x) sees ONE root of multiplicity n and
+  // converges linearly with ratio (n - 1) / n -- it ran into its iteration cap with the fp64 start (2^-48) still in place
+  // (found by the strictly feasible fixture of round 6: tests/golden/synthetic/C4f_x0.25_to_termination.json, iteration 81).
+  // T - c I has the same eigenvectors and its own scale: the cluster is resolved by the fp64 bisection and Newton is
+  // quadratic again.  The subtraction is exact to 2^-(32 NL) of the entries, which is all lambda_min can be known to.
+  const Mw<NL> shift = mw::load<NL>(D.p, od);
+  for(int i = 0; i < n; ++i)
+    mw::store<NL>(D.p, od + i, mw::sub(mw::load<NL>(D.p, od + i), shift));
   // common binary scale for the fp64 image; E := E^2
   int emax = mw::EZERO;
   for(int i = 0; i < n; ++i)
@@ -4394,7 +5266,7 @@ __global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double 
     }
   if(emax == mw::EZERO)
     {
-      mw::store<NL>(lam, q, mw::zero<NL>());
+      mw::store<NL>(lam, q, shift); // T = c I
       return;
     }
   for(int i = 0; i < n; ++i)
@@ -4434,8 +5306,9 @@ __global__ void __launch_bounds__(EIG_T) k_tridiag_min(Batch D, Batch E, double 
   // multi-word Newton on p(x) = det(T - x): x += -1 / sum_i q_i'/q_i, on a ladder of mantissa widths (TridiagLadder):
   // quadratic convergence doubles the correct bits per step, so every step runs at the width it can fill
   const Mw<NL> start = x;
-  TridiagLadder<NL, NL>::run(D, E, od, oe, n, start, x, span, emax);
-  mw::store<NL>(lam, q, x);
+  bool clustered = false;
+  TridiagLadder<NL, NL>::run(D, E, od, oe, n, start, x, span, emax, clustered);
+  mw::store<NL>(lam, q, mw::add(x, shift));
 }
 
 // (max diag / min diag) per matrix: cholesky_condition_number.hxx:8-37 without the

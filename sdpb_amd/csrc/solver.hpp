@@ -204,6 +204,7 @@ public:
   virtual std::string op_scalar(const std::string &op, const char *a, const char *b) = 0;
   virtual std::string op_int_syrk(int rows, int cols, const char *ints_colmajor) = 0;
   virtual std::string op_syrk_Q(int rows, int cols, const char *P_colmajor) = 0;
+  virtual std::string op_min_eigenvalue(int n, const char *A_colmajor) = 0;
 };
 
 // kernel launches of the solver whose entry point is running on this thread (round-4 advisor: the figure in timers_json
@@ -260,10 +261,15 @@ template <int NL> class Solver : public SolverBase
   static constexpr int ACCW = 2 * FX + 2;
   static constexpr bool SYRK_TOOM4 = fx_toom4<FX>();         // seven (FX/4)^2 products per row pair (k_syrk_fx2<.., true> + k_syrk4_finish)
   static constexpr bool SYRK_TOOM4K = fx_toom4k<FX>();       // ... and one Karatsuba level below them: 21 (FX/8)^2 products (k_syrk_fx3)
+  static constexpr bool SYRK_TOOM5K = fx_toom5k<FX>();       // Toom-5 x Karatsuba on 28-bit limbs, lazy carries: 27 products of 2 x 2 limbs (k_syrk_fx3 in lazy mode + k_syrk5_finish)
+  static constexpr int SYRK_NPROD = fx_nprod<FX>();          // products per row pair of k_syrk_fx3
   static constexpr int SYRK_EDGE = syrk_tile_edge<FX>();     // output tile of the syrk kernel in use
   static constexpr unsigned SYRK_SPLIT_ROWS = SYRK_TOOM4K ? 2560u : 0u; // rows per row split of k_syrk_fx3 at most (kernels.hpp: syrk_row_splits)
   static constexpr bool SYRK_TWO_LEVEL = fx_two_level<FX>() || SYRK_TOOM4; // piece-major image: nine (two Karatsuba levels) or seven pieces
-  static constexpr int SYRK_PART_PLANES = SYRK_TOOM4K ? 21 * (2 * (FX / 8) + 1) : SYRK_TOOM4 ? 7 * (2 * (FX / 4) + 1) : ACCW; // planes one row split writes
+  static constexpr int SYRK_PART_PLANES = SYRK_TOOM4K ? SYRK_NPROD * fx_part_limbs<FX>() : SYRK_TOOM4 ? 7 * (2 * (FX / 4) + 1) : ACCW; // planes one row split writes
+  // words per column of the bias terms of the signed evaluation points (k_fx_colsum4_final / k_fx_colsum5_final), of a slice's column sums
+  static constexpr size_t TOOMU_WORDS = SYRK_TOOM5K ? (size_t)3 * T5_Z : (size_t)2 * (2 * (FX / 4) + 2);
+  static constexpr size_t COLSUM_WORDS = SYRK_TOOM5K ? 25 : FX + 8; // 5 x 5, or 2 (FX/2 + 2) / 4 (FX/4 + 2) limbs per column and slice
   // rows per LDS chunk: k_syrk_fx2 stages one piece group of 32 rows per pass; k_syrk_fx 3 FX/2 planes x RB rows
 #ifndef SDPB_SYRK2_RBG
 #define SDPB_SYRK2_RBG (FX >= 32 ? 16 : 32)
@@ -306,6 +312,13 @@ template <int NL> class Solver : public SolverBase
   DevArray b_, y_, dy_, rp_, norms_, invnorms_, Q_, invdQ_, part_, red_, red2_, lam_, lam2_, ratio_, scal_;
   DevBuf<uint32_t> fx_, acc_, syrk_tiles_, colsum_partial_, syrk_part_, toomU_;
   DevBuf<uint32_t> acc2_; // partial G of the input windows after the first (image in several row chunks: q_window())
+  // P = L^{-1} B with the trailing updates as fixed-point tile dot products (kernels.hpp: k_td_image_L, k_trsm_rlt_panel_td):
+  // images of the tiles of every L_j below its diagonal blocks, their row exponents and limb sums, tile offsets per block
+  bool use_td_ = false;
+  DevBuf<int> td_tile_off_;
+  DevBuf<uint32_t> td_img_, td_sum_;
+  DevBuf<int32_t> td_exp_;
+  int td_max_tiles_ = 0;
   int num_cus_ = 256;
   unsigned colsum_slices_ = 1;
   DevBuf<double> eigF_, eigF2_;
@@ -791,13 +804,38 @@ private:
     lam2_.alloc(std::max(2 * Jl_, 1), NL);
     ratio_.alloc((size_t)5 * std::max(Jl_, 1) + 1, NL);
     scal_.alloc(S_COUNT, NL);
+    if constexpr(td_trsm_enabled<NL>())
+      {
+        // SDPB_HIP_TILEDOT=0: the float path everywhere (A/B measurements, parity comparisons)
+        use_td_ = true;
+        if(const char *e = std::getenv("SDPB_HIP_TILEDOT"))
+          use_td_ = std::atoi(e) != 0;
+        std::vector<int> off;
+        size_t tiles = 0;
+        for(const BlockDesc &bd : blk_)
+          {
+            off.push_back((int)tiles);
+            const int nt = td_tiles_of(bd.P);
+            tiles += nt;
+            td_max_tiles_ = std::max(td_max_tiles_, nt);
+          }
+        use_td_ = use_td_ && tiles > 0;
+        if(use_td_)
+          {
+            constexpr size_t WT = td::limbs<NL>();
+            td_tile_off_.upload(off);
+            td_img_.alloc(tiles * PB * PB * WT);
+            td_sum_.alloc(tiles * PB * WT);
+            td_exp_.alloc(tiles * PB);
+          }
+      }
     // (the fixed-point image of P' is planned last, with the partial planes: plan_syrk_part())
     acc_stride_ = (size_t)N_ * N_ + N_; // N x N outputs + N column sums (k_fx_colsum)
     acc_.alloc(acc_stride_ * ACCW);
     if(SYRK_TOOM4)
-      toomU_.alloc((size_t)2 * (2 * (FX / 4) + 2) * N_);
+      toomU_.alloc(TOOMU_WORDS * N_);
     colsum_slices_ = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv(Ptot_, 64)));
-    colsum_partial_.alloc((size_t)colsum_slices_ * (FX + 8) * N_); // 2 (FX/2 + 2) or 4 (FX/4 + 2) limbs per column and slice
+    colsum_partial_.alloc((size_t)colsum_slices_ * COLSUM_WORDS * N_);
     syrk_tiles_.upload(syrk_tile_order(N_, 0, nullptr, SYRK_EDGE));
     if(world_ > 1)
       {
@@ -989,8 +1027,8 @@ public:
     ss << (first ? "" : ", ") << "\"kernel.k_syrk_fx.ms\": " << syrk_kernel_ms_ << ", \"kernel.k_syrk_fx.launches\": " << syrk_launches_
        << ", \"kernel.k_syrk_fx.algorithmic_bytes\": " << (fx_bytes + acc_bytes)
        << ", \"kernel.k_syrk_fx.limb_macs\": "
-       << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TOOM4K ? 21.0 / 64 : SYRK_TOOM4 ? 7.0 / 16 : SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 21 (FX/8)^2, 7 or 9 (FX/4)^2, or 3 (FX/2)^2 per product
-       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TOOM4 ? 0 : SYRK_TWO_LEVEL ? 2 : 1) << ", \"kernel.k_syrk_fx.toom4\": " << (SYRK_TOOM4 ? 1 : 0) << ", \"kernel.k_syrk_fx.toom4k\": " << (SYRK_TOOM4K ? 1 : 0)
+       << (double)Ptot_ * N_ * (N_ + 1) / 2 * FX * FX * (SYRK_TOOM5K ? 27.0 / 64 : SYRK_TOOM4K ? 21.0 / 64 : SYRK_TOOM4 ? 7.0 / 16 : SYRK_TWO_LEVEL ? 9.0 / 16 : 0.75) // executed: 21 (FX/8)^2, 7 or 9 (FX/4)^2, or 3 (FX/2)^2 per product
+       << ", \"kernel.k_syrk_fx.karatsuba_levels\": " << (SYRK_TOOM4 ? 0 : SYRK_TWO_LEVEL ? 2 : 1) << ", \"kernel.k_syrk_fx.toom4\": " << (SYRK_TOOM4 ? 1 : 0) << ", \"kernel.k_syrk_fx.toom4k\": " << (SYRK_TOOM4K ? 1 : 0) << ", \"kernel.k_syrk_fx.toom5k_lazy_carries\": " << (SYRK_TOOM5K ? 1 : 0)
        << ", \"host_syncs\": " << host_syncs_ << ", \"launches\": " << launches_
        << ", \"iterations\": " << iteration_ << ", \"comm.world\": " << world_ << ", \"comm.ranks\": " << (comm_ ? comm_->ranks() : (world_ == 1 ? 1 : 0))
        << ", \"comm.owned_blocks\": " << Jl_ << ", \"comm.owned_rows\": " << Ptot_ << ", \"comm.allgather_calls\": " << xc_allgather_calls_
@@ -1458,6 +1496,21 @@ private:
     for(int p = 0; p < (int)cdiv(max_n, PB); ++p)
       launch(k_trsm_rlt_panel<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, s, p, cyc);
   }
+  // the same for the Schur blocks (P = L^{-1} B): trailing updates as fixed-point tile dot products where the build has them
+  void trsm_rlt_schur(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n, unsigned long long *cyc, const DevArray *src)
+  {
+    if constexpr(td_trsm_enabled<NL>())
+      if(use_td_)
+        {
+          const mw::CPtr s = src ? src->cptr() : mw::CPtr(X.p.base, X.p.stride);
+          launch(k_td_image_L<NL>, dim3(td_max_tiles_, X.count), dim3(WG), stream_, L, Li, (const int *)td_tile_off_.p, td_img_.p, td_exp_.p, td_sum_.p);
+          for(int p = 0; p < (int)cdiv(max_n, PB); ++p)
+            launch(k_trsm_rlt_panel_td<NL>, dim3(cdiv(max_rows, TR), X.count), dim3(WG), stream_, L, Li, X, s, p, cyc, (const int *)td_tile_off_.p,
+                   (const uint32_t *)td_img_.p, (const int32_t *)td_exp_.p, (const uint32_t *)td_sum_.p);
+          return;
+        }
+    trsm_rlt(L, Li, X, max_rows, max_n, cyc, src);
+  }
   // X := X L^{-1}
   void trsm_rln(const Batch &L, const Batch &Li, const Batch &X, int max_rows, int max_n)
   {
@@ -1656,7 +1709,7 @@ private:
     }
     {
       Timer t(this, "initializeSchurComplementSolver.Q.solve");
-      trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, block_clock(1), &BT_); // reads B, writes P
+      trsm_rlt_schur(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, block_clock(1), &BT_); // reads B, writes P
     }
     // Optional (off, see overlap_syrk_): with one rank the whole Q chain — norms, fixed-point image,
     // syrk, restore, Cholesky(Q) — can run on the side stream while the main stream goes on to the
@@ -1806,9 +1859,9 @@ private:
     if(const char *e = std::getenv("SDPB_HIP_SYRK_GSPLIT"))
       {
         const int g = std::atoi(e);
-        return g == 1 || g == 7 ? g : 21;
+        return g == 1 ? 1 : (g == 7 || g == 9) ? SYRK_NPROD / 3 : SYRK_NPROD;
       }
-    return 21; // measured (profiles/r04s_syrk3_variants.txt): C4 101.6 ms against 102.8 with 7, C3 1.23 against 1.55 ms
+    return SYRK_NPROD; // (21 or 27: one product per workgroup) measured (profiles/r04s_syrk3_variants.txt): C4 101.6 ms against 102.8 with 7, C3 1.23 against 1.55 ms
   }
   // The plan of one syrk_G call: the tile list is walked in chunks; every chunk is one product launch + its finishing
   // kernels over tile-packed partial planes (kernels.hpp: syrk_packed_decode) that fit `budget_words` of `part`.
@@ -2019,11 +2072,15 @@ private:
             if constexpr(SYRK_TOOM4K)
               if(nsplit > 1)
                 {
-                  launch(k_syrk3_sum_splits<FX>, dim3(cdiv(total, WG), 21), dim3(WG), stream_, part.p, nsplit, ps, tl, total, N, col0, col1);
+                  launch(k_syrk3_sum_splits<FX>, dim3(cdiv(total, WG), SYRK_NPROD), dim3(WG), stream_, part.p, nsplit, ps, tl, total, N, col0, col1);
                   nsum = 1;
                 }
-            launch(k_syrk4_finish<FX>, dim3(cdiv(total, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsum, ps, tl, total,
-                   (const uint32_t *)toomU, acc, acc_stride, N, col0, col1);
+            if constexpr(SYRK_TOOM5K)
+              launch(k_syrk5_finish<FX>, dim3(cdiv(total, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsum, ps, tl, total,
+                     (const uint32_t *)toomU, acc, acc_stride, N, col0, col1);
+            else
+              launch(k_syrk4_finish<FX>, dim3(cdiv(total, WG)), dim3(WG), stream_, (const uint32_t *)part.p, nsum, ps, tl, total,
+                     (const uint32_t *)toomU, acc, acc_stride, N, col0, col1);
             continue;
           }
         else if constexpr(SYRK_TWO_LEVEL)
@@ -2046,6 +2103,13 @@ private:
       {
         if(!toomU)
           throw SolverError(4, "syrk_column_sums: the Toom-4 image needs a buffer for its column terms");
+        if constexpr(SYRK_TOOM5K)
+          {
+            launch(k_fx_colsum5<FX>, dim3(cdiv(N, 64), slices), dim3(WG), stream_, fx, fx_stride, nrows, N, rows_per_slice, partial);
+            launch(k_fx_colsum5_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride, toomU,
+                   (unsigned long long)nrows);
+            return;
+          }
         launch(k_fx_colsum2<FX, true>, dim3(cdiv(N, 64), slices), dim3(WG), stream_, fx, fx_stride, nrows, N, rows_per_slice, partial);
         launch(k_fx_colsum4_final<FX>, dim3(cdiv(N, WG)), dim3(WG), stream_, (const uint32_t *)partial, (int)slices, N, acc, acc_stride, toomU,
                (unsigned long long)nrows);
@@ -2910,7 +2974,7 @@ public:
         for(int r = 0; r < std::max(reps, 1); ++r)
           {
             HIP_CHECK(hipEventRecord(e0, stream_));
-            trsm_rlt(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, nullptr, &BT_);
+            trsm_rlt_schur(schurB(), Batch{LiS_.ptr(), d_schur_.p, Jl_}, btB(PT_), N_, max_P_, nullptr, &BT_);
             HIP_CHECK(hipEventRecord(e1, stream_));
             HIP_CHECK(hipEventSynchronize(e1));
             float ms = 0;
@@ -2935,7 +2999,7 @@ public:
         uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        p[i] = (uint32_t)(z >> 33);
+        p[i] = (uint32_t)(z >> (SYRK_TOOM5K ? 37 : 33)); // (limbs of the lazy-carry image are < 2^28)
       });
     }
     const size_t as = (size_t)cols * cols + cols;
@@ -2945,7 +3009,7 @@ public:
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
     DevBuf<uint32_t> tu; // column terms of the Toom-4 image (zeros: the timing does not depend on them)
-    tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
+    tu.alloc(TOOMU_WORDS * cols);
     HIP_CHECK(hipMemsetAsync(tu.p, 0, tu.n * sizeof(uint32_t), stream_));
     syrk_G(fx.p, fxs, (unsigned)rows, cols, acc.p, as, (const uint32_t *)tl.p, part, tu.p, -1, 0, -1, fx.n); // warm-up (sizes `part`)
     HIP_CHECK(hipEventRecord(e0, stream_));
@@ -3001,9 +3065,9 @@ public:
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
-    partial.alloc((size_t)slices * (FX + 8) * cols);
+    partial.alloc((size_t)slices * COLSUM_WORDS * cols);
     DevBuf<uint32_t> tu;
-    tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
+    tu.alloc(TOOMU_WORDS * cols);
     tl.upload(syrk_tile_order(cols, 0, nullptr, SYRK_EDGE));
     syrk_G_windows(win, (unsigned)rows, cols, fx, acc.p, as, acc2, partial.p, (const uint32_t *)tl.p, spart, tu.p,
                    [&](size_t r0, unsigned nr) {
@@ -3029,6 +3093,33 @@ public:
         out += "\n";
       }
     return out;
+  }
+
+  // min_eigenvalue.cxx:8-33 as an operator: the smallest eigenvalue of a symmetric n x n matrix (column-major decimals) with
+  // the kernels of the step length -- Householder tridiagonalisation (k_tridiag), then fp64 bisection + multi-word Newton on the
+  // shifted tridiagonal matrix (k_tridiag_min).  The reference calls El::HermitianEig and takes El::Min.
+  std::string op_min_eigenvalue(int n, const char *txt) override
+  {
+    if(n <= 0)
+      throw SolverError(4, "op_min_eigenvalue: n must be positive");
+    DevArray A, D, E, lam;
+    A.alloc((size_t)n * n, NL);
+    D.alloc(n, NL);
+    E.alloc(n, NL);
+    lam.alloc(1, NL);
+    upload<NL>(A, 0, parse_list(txt, (size_t)n * n, "A"));
+    DevBuf<MatDesc> dm, dv;
+    dm.upload(std::vector<MatDesc>{MatDesc{0, n, n, n, 0}});
+    dv.upload(std::vector<MatDesc>{MatDesc{0, n, 1, n, 0}});
+    DevBuf<int> ids;
+    ids.upload(std::vector<int>{0});
+    DevBuf<double> F;
+    F.alloc(2 * ((size_t)n + 1));
+    const Batch Ab{A.ptr(), dm.p, 1}, Db{D.ptr(), dv.p, 1}, Eb{E.ptr(), dv.p, 1};
+    launch(k_tridiag<NL, 128>, dim3(1), dim3(128), stream_, Ab, Db, Eb, (const int *)ids.p);
+    launch(k_tridiag_min<NL>, dim3(1), dim3(EIG_T), stream_, Db, Eb, F.p, F.p + n + 1, lam.ptr());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return mw::to_decimal<NL>(download<NL>(lam, 0, 1)[0]);
   }
 
   // Exact integer syrk of a rows x cols integer matrix (column-major decimal
@@ -3079,9 +3170,9 @@ public:
     const size_t as = (size_t)cols * cols + cols;
     acc.alloc(as * ACCW);
     const unsigned slices = (unsigned)std::min<size_t>(128, std::max<size_t>(1, cdiv((size_t)rows, 64)));
-    partial.alloc((size_t)slices * (FX + 8) * cols);
+    partial.alloc((size_t)slices * COLSUM_WORDS * cols);
     DevBuf<uint32_t> tu;
-    tu.alloc((size_t)2 * (2 * (FX / 4) + 2) * cols);
+    tu.alloc(TOOMU_WORDS * cols);
     DevBuf<uint32_t> tl;
     tl.upload(syrk_tile_order(cols, 0, nullptr, SYRK_EDGE));
     DevBuf<uint32_t> part;

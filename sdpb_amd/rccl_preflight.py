@@ -79,32 +79,47 @@ def run(rank: int, world: int, device: int, exchange_id, timeout: float = 120.0,
     t0 = time.time()
     deadline = t0 + timeout
     child, hexid, lines = None, None, []
+    import queue
+    import threading
+    q: "queue.Queue[str | None]" = queue.Queue()
+
+    def _start(argv):
+        """The child with ONE reader of its pipe: a thread that drains stdout to EOF into the queue (round-5 advisor: the
+        earlier code read the first line through the TextIOWrapper and the rest with communicate(), which reads the raw
+        descriptor -- lines already buffered behind the id, a 'PREFLIGHT OK' among them, were lost, and a reader still
+        blocked in readline() shared the pipe with communicate())."""
+        c = subprocess.Popen(argv, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+        def _reader(pipe=c.stdout):
+            for ln in iter(pipe.readline, ""):
+                q.put(ln)
+            q.put(None)                 # EOF
+
+        threading.Thread(target=_reader, daemon=True).start()
+        return c
+
+    def _next_line():
+        """The next line of the child, None at EOF, "" when the deadline passes first."""
+        try:
+            return q.get(timeout=max(0.05, deadline - time.time()))
+        except queue.Empty:
+            return ""
+
     try:
+        eof = False
         if rank == 0:
-            child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            # The first line is the id (or a failure).  readline() has no timeout, so a reader thread feeds a queue
-            # and THIS thread waits with one (round-4 advisor: a child stalled before "ID ..." -- torch import, HIP
-            # initialisation, ncclGetUniqueId -- would otherwise block rank 0 here and every other rank in exchange_id).
-            import queue
-            import threading
-            q: "queue.Queue[str | None]" = queue.Queue()
-
-            def _reader(pipe=child.stdout):
-                for ln in iter(pipe.readline, ""):
-                    q.put(ln)
-                    if ln.startswith("ID "):
-                        return          # the rest of the output is collected by communicate() below
-                q.put(None)
-
-            threading.Thread(target=_reader, daemon=True).start()
+            child = _start(cmd)
+            # The first lines lead to the id (or a failure).  readline() has no timeout, so THIS thread waits on the queue
+            # with one (round-4 advisor: a child stalled before "ID ..." -- torch import, HIP initialisation,
+            # ncclGetUniqueId -- would otherwise block rank 0 here and every other rank in exchange_id).
             while True:
-                try:
-                    line = q.get(timeout=max(0.05, deadline - time.time()))
-                except queue.Empty:
+                line = _next_line()
+                if line == "":
                     lines.append(f"no id within {timeout:.0f} s")
                     child.kill()
                     break
                 if line is None:
+                    eof = True
                     break
                 lines.append(line.strip())
                 if line.startswith("ID "):
@@ -116,16 +131,21 @@ def run(rank: int, world: int, device: int, exchange_id, timeout: float = 120.0,
                 child.kill()
             return {"ok": False, "seconds": time.time() - t0, "detail": "rank 0 produced no id: " + " | ".join(lines[-3:])}
         if rank != 0:
-            child = subprocess.Popen(cmd + ["--id", hexid], cwd=ROOT, env=env, stdout=subprocess.PIPE,
-                                     stderr=subprocess.STDOUT, text=True)
+            child = _start(cmd + ["--id", hexid])
+        while not eof:                           # the rest of the output, to EOF or to the deadline
+            line = _next_line()
+            if line == "":
+                child.kill()
+                return {"ok": False, "seconds": time.time() - t0, "detail": f"timed out after {timeout:.0f} s: " + " | ".join(lines[-3:])}
+            if line is None:
+                break
+            lines.append(line.strip())
         try:
-            out, _ = child.communicate(timeout=max(1.0, deadline - time.time()))
+            child.wait(timeout=max(1.0, deadline - time.time()))
         except subprocess.TimeoutExpired:
             child.kill()
-            out, _ = child.communicate()
-            tail = " | ".join((lines + (out or "").strip().splitlines())[-3:])
-            return {"ok": False, "seconds": time.time() - t0, "detail": f"timed out after {timeout:.0f} s: {tail}"}
-        lines += (out or "").strip().splitlines()
+            return {"ok": False, "seconds": time.time() - t0, "detail": f"no exit within {timeout:.0f} s: " + " | ".join(lines[-3:])}
+        lines = [l for l in lines if l]
         ok = child.returncode == 0 and any(l.startswith("PREFLIGHT OK") for l in lines)
         return {"ok": ok, "seconds": time.time() - t0, "detail": (lines[-1] if lines else f"exit code {child.returncode}")[:400]}
     except Exception as e:                      # pragma: no cover - the pre-flight must never take the job down

@@ -133,6 +133,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                                        ctypes.c_char_p, ctypes.c_size_t, size_p]
     L.sdpb_hip_op_syrk_Q.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                      ctypes.c_char_p, ctypes.c_size_t, size_p]
+    if hasattr(L, "sdpb_hip_op_min_eigenvalue"):   # (absent only from an older build passed as lib_path for A/B timing)
+        L.sdpb_hip_op_min_eigenvalue.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, size_p]
     ull_p = ctypes.POINTER(ctypes.c_ulonglong)
     L.sdpb_hip_host_encode_u64.argtypes = [ctypes.c_char_p, ctypes.c_int, ull_p]
     L.sdpb_hip_host_decode_u64.argtypes = [ull_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, size_p]
@@ -414,6 +416,10 @@ class SDPSolver:
         diagonal check, restore): lower triangle, column-major decimals."""
         txt = " ".join(str(v) for v in P_colmajor).encode()
         return self._string(self.L.sdpb_hip_op_syrk_Q, rows, cols, txt).split()
+
+    def op_min_eigenvalue(self, n: int, A_colmajor) -> str:
+        """Smallest eigenvalue of a symmetric n x n matrix through the kernels of the step length (min_eigenvalue.cxx:8-33)."""
+        return self._string(self.L.sdpb_hip_op_min_eigenvalue, n, " ".join(str(v) for v in A_colmajor).encode())
 
     def block_timings(self) -> List[int]:
         """Microseconds per iteration for the blocks this rank owns (0 elsewhere); needs profiled iterations."""

@@ -76,9 +76,10 @@ def _fx(nl: int):
         fx += 4 - fx % 4
     toom4 = fx >= 16 and fx % 4 == 0
     toom4k = fx in (16, 24, 32)
+    toom5k = fx == 16          # kernels.hpp: fx_toom5k (Toom-5 x Karatsuba on 28-bit limbs: 27 pieces of two words, 27 x 5 limbs per split)
     two = fx % 4 == 0
-    words = 21 * (fx // 8) if toom4k else 7 * (fx // 4) if toom4 else 9 * (fx // 4) if two else 3 * (fx // 2)
-    planes = 21 * (2 * (fx // 8) + 1) if toom4k else 7 * (2 * (fx // 4) + 1) if toom4 else 2 * fx + 2
+    words = 54 if toom5k else 21 * (fx // 8) if toom4k else 7 * (fx // 4) if toom4 else 9 * (fx // 4) if two else 3 * (fx // 2)
+    planes = 135 if toom5k else 21 * (2 * (fx // 8) + 1) if toom4k else 7 * (2 * (fx // 4) + 1) if toom4 else 2 * fx + 2
     rb = (16 if fx >= 32 else 32) if two else (16 if fx <= 24 else 8)
     waves = 3 if toom4k else (3 if fx <= 16 else 2)
     return fx, words, 32 if toom4k else 16, planes, rb, waves, toom4, toom4k

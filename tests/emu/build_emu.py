@@ -54,7 +54,10 @@ def _run(cmd):
 
 
 VARIANTS = {"notoom4": (["-DSDPB_SYRK_NO_TOOM4"], (18,)),    # name -> (extra flags, limb counts): documented build options kept alive
-            "notoom4k": (["-DSDPB_SYRK_NO_TOOM4K"], (18,))}
+            "notoom4k": (["-DSDPB_SYRK_NO_TOOM4K"], (18,)),
+            "notoom5k": (["-DSDPB_SYRK_NO_TOOM5K"], (18,)),   # Toom-4 x Karatsuba (k_syrk_fx3 with carries) at 512 bits: the 487-bit image of rounds 4-5
+            "dev18": ([], (18,)),
+            "trace18": (["-DSDPB_TRACE_TRIMIN"], (18,))}                             # developer iterations: the 512-bit width alone
 
 
 def build(force=False, panel=None, variant=None):

@@ -245,3 +245,51 @@ def check_schur_hook_against_oracle(lib_path, name="singlet_cT", warm_iterations
     s.close()
     o.close()
     return max(report.values())
+
+
+def check_min_eigenvalue(solver, oracle, limbs, n=40, seed=5):
+    """min_eigenvalue.cxx:8-33 as an operator on spectra that whole iterations reach only late in a convergent run: every
+    eigenvalue of L^-1 dX L^-T within 2^-k of -(1 - beta) (then both step lengths are gamma / (1 - beta), step.cxx:202-206).
+    A = c I + 2^-k S with S random symmetric: Newton on det(T - x) sees one root of multiplicity n unless the matrix is
+    shifted first (kernels.hpp: k_tridiag_min) -- the unshifted iteration kept the 2^-48 of its fp64 start (found on the
+    strictly feasible C4f x0.25 fixture, iteration 81).  Also: a generic matrix, c I itself, a half-clustered spectrum, n = 1, 2.
+    Bar: 2^-(32 limbs - 64) of the largest entry of A."""
+    import random
+    from fractions import Fraction
+    rng = random.Random(seed)
+
+    def dec(fr):
+        import decimal
+        with decimal.localcontext() as ctx:
+            ctx.prec = 900
+            return format(decimal.Decimal(fr.numerator) / decimal.Decimal(fr.denominator), "f")
+
+    def sym(m, scale):
+        S = [[Fraction(0)] * m for _ in range(m)]
+        for i in range(m):
+            for j in range(i + 1):
+                S[i][j] = S[j][i] = Fraction(rng.randrange(-2 ** 40, 2 ** 40), 2 ** 40) * scale
+        return S
+    c = Fraction(-9, 10)
+    cases = []
+    for k in (0, 12, 40, 90, 200, 400):
+        S = sym(n, Fraction(1, 2 ** k))
+        cases.append((f"c I + 2^-{k} S", n, [[S[i][j] + (c if i == j else 0) for j in range(n)] for i in range(n)]))
+    cases.append(("c I", n, [[c if i == j else Fraction(0) for j in range(n)] for i in range(n)]))
+    S, R = sym(n // 2, Fraction(1, 2 ** 70)), sym(n, Fraction(1, 2 ** 70))
+    half = [[R[i][j] for j in range(n)] for i in range(n)]
+    for i in range(n):
+        half[i][i] += c if i < n // 2 else Fraction(rng.randrange(1, 2 ** 20), 2 ** 18)
+    cases.append(("half of the spectrum clustered", n, half))
+    cases.append(("n = 1", 1, [[Fraction(-7, 3)]]))
+    cases.append(("n = 2", 2, [[Fraction(1, 3), Fraction(5, 7)], [Fraction(5, 7), Fraction(-2, 9)]]))
+    worst = float("-inf")
+    for name, m, A in cases:
+        col = [dec(A[i][j]) for j in range(m) for i in range(m)]
+        got, want = mpmath.mpf(solver.op_min_eigenvalue(m, col)), mpmath.mpf(oracle.min_eigenvalue(m, col))
+        scale = max(abs(mpmath.mpf(A[i][j].numerator) / A[i][j].denominator) for i in range(m) for j in range(m))
+        d = abs(got - want) / scale
+        l2 = float(mpmath.log(d, 2)) if d > 0 else float("-inf")
+        assert l2 <= -(32 * limbs - 64), (name, l2)
+        worst = max(worst, l2)
+    return worst

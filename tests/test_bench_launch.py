@@ -91,3 +91,35 @@ def test_parity_gate_of_the_bench_covers_every_timed_iteration_and_the_terminati
     assert bench.parity_gate(_Replay(fx, perturb=(40, 260)), "C4", 1.0, 512)["passed"]
     assert not bench.parity_gate(_Replay(fx, perturb=(40, 250)), "C4", 1.0, 512)["passed"]
     assert not bench.parity_gate(_Replay(fx, wrong_reason=True), "C4", 1.0, 512)["passed"]
+
+
+def test_preflight_reads_the_child_through_one_reader(monkeypatch):
+    """sdpb_amd/rccl_preflight.run with stand-in children (no GPU): (1) a child that writes its id and its verdict in ONE burst --
+    the lines buffered behind the id must not be lost (round-5 advisor: the first line went through the TextIOWrapper, the rest
+    through communicate() on the raw descriptor); (2) a child that never produces an id ends the wait at the deadline and is
+    killed; (3) a rank other than 0 receives the id and reports its own child's verdict; (4) a non-zero exit is not ok."""
+    import subprocess
+    import sys
+    import time
+    from sdpb_amd import rccl_preflight as pf
+    real_popen = subprocess.Popen
+    script = {}
+
+    def fake_popen(argv, **kw):
+        return real_popen([sys.executable, "-c", script["src"]] + [a for a in argv if a.startswith("--id")] + argv[-1:], **kw)
+
+    monkeypatch.setattr(pf.subprocess, "Popen", fake_popen)
+    script["src"] = "import sys; sys.stdout.write('warming up\\nID abcd\\nsome chatter\\nPREFLIGHT OK {}\\n'); sys.stdout.flush()"
+    seen = {}
+    r = pf.run(0, 2, 0, lambda h: seen.setdefault("id", h), timeout=20.0)
+    assert r["ok"] and seen["id"] == "abcd" and r["detail"].startswith("PREFLIGHT OK"), r
+    script["src"] = "import time; print('starting', flush=True); time.sleep(60)"
+    t0 = time.time()
+    r = pf.run(0, 2, 0, lambda h: h, timeout=1.5)
+    assert not r["ok"] and "no id" in r["detail"] and time.time() - t0 < 10, r
+    script["src"] = "import sys; print('PREFLIGHT OK {}' if '--id' in sys.argv else 'no id given', flush=True)"
+    r = pf.run(1, 2, 0, lambda h: "ef01", timeout=20.0)
+    assert r["ok"], r
+    script["src"] = "import sys; print('ID 12', flush=True); print('PREFLIGHT OK {}', flush=True); sys.exit(3)"
+    r = pf.run(0, 2, 0, lambda h: h, timeout=20.0)
+    assert not r["ok"], r

@@ -31,7 +31,7 @@ _INT_SYRK = [(128, 37, 21, None), (128, 70, 21, "3"), (512, 45, 18, None), (512,
              (1024, 35, 49, None), (1280, 36, 17, None), (1280, 70, 17, "2")]
 # a memory budget (bytes) below the partial planes of the whole output: Q' in chunks of output tiles (Solver::syrk_plan; 32 x 32
 # tiles at 512 ... 1024 bits, 16 x 16 else) -- the analogue of the reference's output windows (bigint_syrk_blas.cxx:200-220)
-_INT_SYRK_CHUNKED = [(512, 70, 81, "2", 1.0e6), (512, 100, 97, None, 5.0e5), (128, 70, 41, "3", 2.5e4), (1024, 40, 49, "2", 1.6e6),
+_INT_SYRK_CHUNKED = [(512, 70, 81, "2", 1.0e6), (512, 100, 97, None, 6.0e5), (128, 70, 41, "3", 2.5e4), (1024, 40, 49, "2", 1.6e6),
                      (1280, 70, 33, "2", 7.0e5), (768, 37, 45, "2", 1.3e6)]
 
 
@@ -46,11 +46,11 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, budget, monke
     sdp, meta, _, _ = parity.load_case("1d")
     s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
     o = Oracle(sdp, precision)
-    fb = s.fx_frac_bits           # 32 FX - 25 (Toom-4 x Karatsuba: FX = 16, 24, 32), - 17 (Toom-4: FX = 40, 48), - 7 (two Karatsuba levels: other FX % 4 == 0), else - 3
+    fb = s.fx_frac_bits           # 509 (Toom-5 x Karatsuba on 28-bit limbs: FX = 16), 32 FX - 25 (Toom-4 x Karatsuba: FX = 24, 32), - 17 (Toom-4: FX = 40, 48), - 7 (two Karatsuba levels: other FX % 4 == 0), else - 3
     fx = s.limbs - 2
     if fx >= 14 and fx % 4:
         fx += 4 - fx % 4      # kernels.hpp: fx_limbs — from 400 bits up the image is padded to a multiple of four limbs
-    assert fb == 32 * fx - (25 if fx in (16, 24, 32) else 17 if fx in (40, 48) else 7 if fx % 4 == 0 else 3)
+    assert fb == (509 if fx == 16 else 32 * fx - (25 if fx in (24, 32) else 17 if fx in (40, 48) else 7 if fx % 4 == 0 else 3))
     rng = random.Random(7)
     vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
     vals[5] = 0
@@ -61,7 +61,8 @@ def test_emulated_int_syrk_is_exact(precision, rows, cols, splits, budget, monke
     # exactly at / next to the split points of the image a' = v + 2^fb (Karatsuba: first and second level;
     # Toom-4: the piece boundaries at multiples of 8 fx - 4 bits)
     # (Toom-4 x Karatsuba: pieces of 8 fx - 6 bits, halves of 4 fx - 1 bits)
-    for k, bit in enumerate((8 * fx - 6, 16 * fx - 12, 24 * fx - 18, 4 * fx - 1, 12 * fx - 7) if fx in (16, 24, 32) else
+    for k, bit in enumerate((102, 204, 306, 408, 55, 110, 28, 83) if fx == 16 else      # Toom-5 pieces of 102 bits, halves of 55 bits, 28-bit limbs
+                            (8 * fx - 6, 16 * fx - 12, 24 * fx - 18, 4 * fx - 1, 12 * fx - 7) if fx in (24, 32) else
                             (8 * fx - 4, 16 * fx - 8, 24 * fx - 12, 8 * fx - 5) if fx in (40, 48) else
                             (16 * fx - 1, 16 * fx - 3, 8 * fx - 1, 24 * fx - 4)):
         vals[15 + 2 * k] = 2 ** bit - 2 ** fb if bit < fb else 2 ** (bit - 1)
@@ -249,6 +250,27 @@ def test_documented_build_without_the_karatsuba_level_keeps_working():
     o.close()
 
 
+def test_documented_build_without_toom5_keeps_working():
+    """-DSDPB_SYRK_NO_TOOM5K (Toom-4 x Karatsuba with carried 96-bit column sums, the kernel of
+    rounds 4-5 and its 487-bit image at 512 bits) stays a working option: exact product over several 32-column tiles and every
+    quadrant mask, forced row splits, and the Q stage."""
+    import random
+    from oracle.oracle import Oracle
+    sdp, meta, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, 512, lib_path=libs.emu_lib(variant="notoom5k"))
+    assert s.limbs == 18 and s.fx_frac_bits == 32 * 16 - 25
+    o = Oracle(sdp, 512)
+    rng = random.Random(17)
+    rows, cols, fb = 70, 81, s.fx_frac_bits
+    vals = [rng.randrange(-(2 ** fb) + 1, 2 ** fb) for _ in range(rows * cols)]
+    vals[3], vals[4], vals[5] = 2 ** fb - 1, -(2 ** fb) + 1, 0
+    got, want = s.op_int_syrk(rows, cols, vals), o.int_syrk(rows, cols, vals)
+    assert all(got[i + j * cols] == want[j + i * cols] for j in range(cols) for i in range(j, cols))
+    assert parity.check_syrk_Q(s, 512) <= -(512 - 40)
+    s.close()
+    o.close()
+
+
 def test_emulated_library_matches_oracle_on_dim6_blocks():
     """BASELINE.json config 5 shape (m_j = 6, K_j = 2: 21 (r,s) pairs per block) at reduced size
     and precision 512: exercises the (r,s) tile decoding of pairings, Schur assembly, constraint
@@ -378,5 +400,17 @@ def test_emulated_big_and_ragged_blocks_match_the_oracle():
         assert not s.iterate() and not o.iterate()
         bad, w = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=256)
         assert not bad and w <= -280, (it + 1, w, bad)
+    s.close()
+    o.close()
+
+
+@pytest.mark.parametrize("precision", [128, 512, 768])
+def test_emulated_min_eigenvalue_of_clustered_spectra(precision):
+    from oracle.oracle import Oracle
+    sdp, _, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
+    o = Oracle(sdp, 2 * precision + 256)     # reference values at more than twice the width
+    worst = parity.check_min_eigenvalue(s, o, s.limbs, n=24)
+    print(f"lambda_min at {precision} bits: worst 2^{worst:.1f} of the largest entry")
     s.close()
     o.close()

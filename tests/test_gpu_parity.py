@@ -73,11 +73,24 @@ def test_iterations_at_the_default_precision_400():
     sdp, meta, _, _ = parity.load_case("singlet_cT")
     o = Oracle(sdp, 400, meta["params"], param_prec=64)
     s = _solver(sdp, 400, parity.reference_params(meta["params"], o))
-    assert s.limbs == 16 and s.fx_frac_bits == 487
+    assert s.limbs == 16 and s.fx_frac_bits == 509   # (Toom-5 x Karatsuba image: round 6; 487 with -DSDPB_SYRK_NO_TOOM5K)
     for it in range(12):
         assert not s.iterate() and not o.iterate()
         bad, _ = parity.compare_iteration(s.scalars(), o.scalars(), tol_bits=200)
         assert not bad, (it + 1, bad)
+    s.close()
+    o.close()
+
+
+# ---- the smallest eigenvalue behind the step lengths, on spectra clustered like those of a run that converges
+@pytest.mark.parametrize("precision", [128, 256, 400, 512, 768, 1024, 1536, 2048])
+def test_min_eigenvalue_of_clustered_spectra(precision):
+    from oracle.oracle import Oracle
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    o = Oracle(sdp, 2 * precision + 256)
+    worst = parity.check_min_eigenvalue(s, o, s.limbs, n=40)
+    print(f"lambda_min at {precision} bits ({s.limbs} limbs): worst 2^{worst:.1f} of the largest entry")
     s.close()
     o.close()
 

@@ -315,3 +315,19 @@ def test_zero_costs_do_not_pile_up_on_rank_zero():
     with pytest.raises(SDPBError, match="Incompatible number of entries"):
         sdp, meta, _, _ = parity.load_case("dfibo")
         SDPSolver(sdp, meta["precision"], lib_path=libs.emu_lib(), block_costs=[1] * (sdp.J + 3))
+
+
+def test_tile_dot_products_are_exact_against_gmp(tmp_path):
+    """sdpb_amd/csrc/tiledot.hpp (the fixed-point tile dot products behind the trailing updates of P = L^-1 B: radix 2^27,
+    biased images, carry-free 64-bit column sums) against exact GMP integers on the host (tests/shim/tiledot_check.cpp): the
+    image is the exact floor, the tile sum misses only the columns that are not formed (< 2^(27 cut + 37)), and the float
+    accumulator ends within 2^-(32 NL - 4) of the exact sum relative to its largest term while the spread of the tile stays
+    inside the spare bits -- for 6, 10, 16, 18, 24 limbs with 32-term tiles and 26 limbs with 16-term tiles."""
+    import subprocess
+    exe = tmp_path / "tiledot_check"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(libs.ROOT, "sdpb_amd", "csrc"), "-I/opt/conda/include",
+                        os.path.join(libs.ROOT, "tests", "shim", "tiledot_check.cpp"), "-o", str(exe), "-l:libgmp.so.10"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count(" 0 failures") == 8, r.stdout + r.stderr
