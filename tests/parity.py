@@ -71,6 +71,18 @@ def compare_iteration(got: dict, want: dict, tol_bits: int = 99, skip_err_below_
     return bad, worst
 
 
+def conditioned_tol_bits(rec: dict, precision: int, tol_bits: int, guard_bits: int = 16) -> int:
+    """The bar an iteration can be held to when its linear algebra is ill-conditioned: two p-bit computations of the same
+    iteration that round in different orders (GMP's mpf products truncate, the device rounds to nearest; sums are taken
+    in different orders) agree to about cond 2^-p, where cond is the larger of the two condition numbers the iteration
+    itself reports (max_block_cond_number: the Cholesky factors of the PSD blocks, Q_cond_number: the Schur complement).
+    The SURVEY 8d bar 2^-(p/2) stays wherever cond < 2^(p/2 - guard); past that (the last iterations of a run that
+    converges to 'found primal-dual optimal solution': block condition 2^296 at 512 bits in the strictly feasible
+    fixture C4f, measured difference cond 2^-(p+38)) the bar is 2^-(p - log2 cond - guard)."""
+    cond = max(mpmath.mpf(rec.get("max_block_cond_number", 1)), mpmath.mpf(rec.get("Q_cond_number", 1)), mpmath.mpf(1))
+    return min(tol_bits, precision - int(mpmath.ceil(mpmath.log(cond, 2))) - guard_bits)
+
+
 DEFAULT_PARAMS = {  # Solver_Parameters.cxx:10-157
     "dualityGapThreshold": "1e-30", "primalErrorThreshold": "1e-30", "dualErrorThreshold": "1e-30",
     "initialMatrixScalePrimal": "1e20", "initialMatrixScaleDual": "1e20",

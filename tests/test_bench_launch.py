@@ -76,7 +76,8 @@ class _Replay:
 def test_parity_gate_of_the_bench_covers_every_timed_iteration_and_the_termination():
     """bench.py's gate on the full-size C4 fixture (round 5: 48 oracle iterations + 'maxComplementarity exceeded' in iteration
     49): a faithful replay passes and is followed to termination; a field that is 2^-260 off in an EARLY iteration fails the
-    tighter bar of the iterations the clock sees although it is inside the whole-run floor 2^-256; the same error late passes;
+    tighter bar of the iterations the clock sees although it is inside the whole-run floor 2^-256; the same error late fails the
+    per-iteration pin to the measured trajectory;
     2^-250 anywhere fails; a different terminate reason fails."""
     sys.path.insert(0, libs.ROOT)
     import bench
@@ -88,9 +89,35 @@ def test_parity_gate_of_the_bench_covers_every_timed_iteration_and_the_terminati
     assert g["passed"] and g["iterations"] == 48 and g["followed_to_termination"] == {"iteration": 49, "reason": "maxComplementarity exceeded"}
     assert len(g["worst_log2_rel_by_iteration"]) == 48 and g["early_iterations_bar"]["first"] == 25
     assert not bench.parity_gate(_Replay(fx, perturb=(7, 260)), "C4", 1.0, 512)["passed"]
-    assert bench.parity_gate(_Replay(fx, perturb=(40, 260)), "C4", 1.0, 512)["passed"]
+    # round 6: every iteration is pinned to what the device was measured at (gate_thresholds.json "#measured_by_iteration",
+    # iteration 40: 2^-330.3) plus 12 bits, so an error in a LATE iteration that the whole-run floor would let through is refused
+    late = bench.parity_gate(_Replay(fx, perturb=(40, 260)), "C4", 1.0, 512)
+    assert not late["passed"] and late["pinned_to_measured_trajectory"] == {"margin_bits": 12.0, "iterations": 48}
+    assert "drift against the measured trajectory" in str(late["violations"])
+    assert bench.parity_gate(_Replay(fx, perturb=(40, 325)), "C4", 1.0, 512)["passed"]
     assert not bench.parity_gate(_Replay(fx, perturb=(40, 250)), "C4", 1.0, 512)["passed"]
     assert not bench.parity_gate(_Replay(fx, wrong_reason=True), "C4", 1.0, 512)["passed"]
+
+
+def test_parity_gate_on_the_run_to_optimality_uses_the_conditioned_bar_only_where_the_iteration_is_ill_conditioned():
+    """The strictly feasible fixture (C4 x0.25 shape, 159 iterations, then 'found primal-dual optimal solution'): the floor
+    2^-(p/2) holds through iteration 142; the last 17 iterations, whose block condition number passes 2^(p/2-16), are held to
+    cond 2^-(p-16) (parity.conditioned_tol_bits) -- and every iteration to the measured trajectory + 12 bits."""
+    sys.path.insert(0, libs.ROOT)
+    import bench
+    from tests import parity
+    with open(bench.fixture_path("C4f", 0.25)) as f:
+        fx = json.load(f)
+    assert fx["terminate_reason"] == "found primal-dual optimal solution" and fx["terminated_in_iteration"] == 160
+    bars = [parity.conditioned_tol_bits(r, 512, 256) for r in fx["iterations"]]
+    assert bars[:142] == [256] * 142 and all(196 <= b < 256 for b in bars[142:]) and bars == sorted(bars, reverse=True)
+    g = bench.parity_gate(_Replay(fx), "C4f", 0.25, 512)
+    assert g["passed"] and g["iterations_on_the_conditioned_bar"] == sum(b < 256 for b in bars)
+    assert g["followed_to_termination"] == {"iteration": 160, "reason": "found primal-dual optimal solution"}
+    assert not bench.parity_gate(_Replay(fx, perturb=(159, 240)), "C4f", 0.25, 512)["passed"]   # inside the conditioned bar, outside the pin
+    assert not bench.parity_gate(_Replay(fx, perturb=(100, 300)), "C4f", 0.25, 512)["passed"]   # inside 2^-256, outside the pin
+    with open(bench.fixture_path("C4", 1.0)) as f:
+        assert all(parity.conditioned_tol_bits(r, 512, 256) == 256 for r in json.load(f)["iterations"])
 
 
 def test_preflight_reads_the_child_through_one_reader(monkeypatch):

@@ -81,7 +81,8 @@ def test_gpu_matches_oracle_fixture_at_full_size(fixture):
     worst = float("-inf")
     for rec in fx["iterations"]:
         assert not s.iterate(), s.terminate_reason
-        bad, w = parity.compare_iteration(s.scalars(), rec, tol_bits=p // 2)
+        # 2^-(p/2), relaxed to cond 2^-(p-16) only where the iteration's own condition numbers pass 2^(p/2-16)
+        bad, w = parity.compare_iteration(s.scalars(), rec, tol_bits=parity.conditioned_tol_bits(rec, p, p // 2))
         worst = max(worst, w)
         assert not bad, f"{fixture} iteration {rec['iteration']}: {bad}"
     if "terminate_reason" in fx:
@@ -91,7 +92,7 @@ def test_gpu_matches_oracle_fixture_at_full_size(fixture):
         assert s.iterate(), f"{fixture}: no termination in iteration {fx['terminated_in_iteration']}"
         assert s.terminate_reason == fx["terminate_reason"]
         for key in ("primalObjective", "dualObjective"):
-            assert parity.log2_rel(s.scalar(key), fx[key]) <= -(p // 2), key
+            assert parity.log2_rel(s.scalar(key), fx[key]) <= -parity.conditioned_tol_bits(fx["iterations"][-1], p, p // 2), key
     print(f"{fixture}: J={sdp.J} N={sdp.N} P_tot={sdp.P_total}: {len(fx['iterations'])} iterations, "
           f"worst log2 rel diff {worst:.1f}" + (f", then '{fx['terminate_reason']}'" if "terminate_reason" in fx else ""))
     s.close()
