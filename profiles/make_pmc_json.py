@@ -25,7 +25,7 @@ def per_kernel(path):
 def main():
     fetch, write, tag = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     main_k = [k for k in fetch if k.startswith("k_syrk_fx")][0]
-    side = [k for k in fetch if k.startswith(("k_syrk4_finish", "k_syrk_reduce", "k_syrk3_sum_splits"))]
+    side = [k for k in fetch if k.startswith(("k_syrk4_finish", "k_syrk5_finish", "k_syrk_reduce", "k_syrk3_sum_splits"))]
     copy = [k for k in fetch if k.startswith("k_copy16")]
     f_kb = fetch[main_k][1]                            # 16 B/lane global_load_lds: counted half
     f_side_kb = sum(fetch[k][1] for k in side)        # 4 B/lane loads of the finishing kernel: counted in full

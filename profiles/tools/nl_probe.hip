@@ -1,0 +1,211 @@
+// nl_probe.hip -- cross-width consistency of the kernels behind the step lengths and the block condition numbers.
+// Round 5 built a 98-limb width (3072 bits) once: arithmetic, exact syrk and image floor passed on the device, whole
+// iterations gave P-step, D-step and max_block_cond_number to 2^-64 of the oracle only.  This probe runs the kernels those
+// three scalars pass through -- k_tridiag, k_tridiag_min, k_reduce<RED_MIN/RED_MAX>, k_diag_ratio, the LDS tree of
+// k_cond_best -- at two widths on the SAME matrices (entries with 64 significant bits: exact at every width) and prints
+// how far the wide result is from the narrow one: a healthy pair agrees to the narrow width's last bits.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPROBE_A=66 -DPROBE_B=98 -DSDPB_PB=16 profiles/tools/nl_probe.hip -o nl_probe
+#include <cstdio>
+#include <vector>
+#include <cmath>
+#include "../../sdpb_amd/csrc/kernels.hpp"
+using namespace sdpb;
+#ifndef PROBE_A
+#define PROBE_A 18
+#endif
+#ifndef PROBE_B
+#define PROBE_B 34
+#endif
+static uint64_t lcg_state = 88172645463325252ull;
+static uint64_t lcg()
+{
+  lcg_state ^= lcg_state << 13;
+  lcg_state ^= lcg_state >> 7;
+  lcg_state ^= lcg_state << 17;
+  return lcg_state;
+}
+template <int NL> Mw<NL> from_bits(uint64_t mant, int e, bool neg)
+{
+  Mw<NL> v = mw::zero<NL>();
+  mant |= 1ull << 63;
+  v.m[NL - 1] = (uint32_t)(mant >> 32);
+  v.m[NL - 2] = (uint32_t)mant;
+  v.e = e;
+  v.neg = neg ? 1u : 0u;
+  return v;
+}
+struct Entry
+{
+  uint64_t mant;
+  int e;
+  bool neg;
+};
+template <int NL> struct Host
+{
+  std::vector<uint32_t> w;
+  size_t n;
+  explicit Host(size_t count) : w((size_t)(NL + 1) * count, 0u), n(count) {}
+  mw::Ptr ptr() { return mw::Ptr{w.data(), n}; }
+};
+template <int NL> struct Dev
+{
+  uint32_t *p = nullptr;
+  size_t n;
+  explicit Dev(size_t count) : n(count)
+  {
+    HIP_CHECK(hipMalloc(&p, (size_t)(NL + 1) * n * 4));
+    HIP_CHECK(hipMemset(p, 0, (size_t)(NL + 1) * n * 4));
+  }
+  ~Dev() { (void)hipFree(p); }
+  mw::Ptr ptr() { return mw::Ptr{p, n}; }
+  void up(Host<NL> &h) { HIP_CHECK(hipMemcpy(p, h.w.data(), h.w.size() * 4, hipMemcpyHostToDevice)); }
+  void down(Host<NL> &h) { HIP_CHECK(hipMemcpy(h.w.data(), p, h.w.size() * 4, hipMemcpyDeviceToHost)); }
+};
+struct Results
+{
+  std::vector<std::vector<uint32_t>> m; // top limbs first
+  std::vector<int> e, neg;
+};
+template <int NL> void push(Results &r, const Mw<NL> &v)
+{
+  std::vector<uint32_t> m(NL);
+  for(int i = 0; i < NL; ++i)
+    m[i] = v.m[NL - 1 - i];
+  r.m.push_back(m);
+  r.e.push_back(v.e);
+  r.neg.push_back((int)v.neg);
+}
+// log2 |a - b| / |a| from the leading limbs the two have in common
+static double log2_rel(const Results &a, const Results &b, size_t i)
+{
+  if(a.e[i] != b.e[i] || a.neg[i] != b.neg[i])
+    return 0.0;
+  const size_t n = std::min(a.m[i].size(), b.m[i].size());
+  for(size_t k = 0; k < n; ++k)
+    if(a.m[i][k] != b.m[i][k])
+      {
+        const double d = std::fabs((double)a.m[i][k] - (double)b.m[i][k]);
+        return -32.0 * (double)k - 32.0 + std::log2(d) + 1.0; // leading limb is normalised: value in [1/2, 1)
+      }
+  return -32.0 * (double)n;
+}
+
+template <int NL> Results run(const std::vector<Entry> &ent, int M, int n)
+{
+  Results out;
+  const size_t per = (size_t)n * n;
+  Host<NL> hA(per * M);
+  for(int q = 0; q < M; ++q)
+    for(int i = 0; i < n; ++i)
+      for(int j = 0; j <= i; ++j)
+        {
+          const Entry &x = ent[(size_t)q * per + (size_t)i * n + j];
+          Mw<NL> v = from_bits<NL>(x.mant, i == j ? 3 : x.e, i == j ? false : x.neg);
+          mw::store<NL>(hA.ptr(), (size_t)q * per + i + (size_t)j * n, v);
+          mw::store<NL>(hA.ptr(), (size_t)q * per + j + (size_t)i * n, v);
+        }
+  Dev<NL> dA(per * M), dD((size_t)n * M + 1), dE((size_t)n * M + 1), dlam(M), dred(512), dres(8), dratio(M);
+  dA.up(hA);
+  std::vector<MatDesc> ha(M), hd(M);
+  std::vector<int> ids(M);
+  for(int q = 0; q < M; ++q)
+    {
+      ha[q] = MatDesc{(unsigned long long)q * per, n, n, n, 0};
+      hd[q] = MatDesc{(unsigned long long)q * n, n, 1, n, 0};
+      ids[q] = q;
+    }
+  MatDesc *da, *dd;
+  int *dids;
+  double *dF;
+  HIP_CHECK(hipMalloc(&da, M * sizeof(MatDesc)));
+  HIP_CHECK(hipMalloc(&dd, M * sizeof(MatDesc)));
+  HIP_CHECK(hipMalloc(&dids, M * sizeof(int)));
+  HIP_CHECK(hipMalloc(&dF, 2 * ((size_t)n * M + 2) * sizeof(double)));
+  HIP_CHECK(hipMemcpy(da, ha.data(), M * sizeof(MatDesc), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(dd, hd.data(), M * sizeof(MatDesc), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(dids, ids.data(), M * sizeof(int), hipMemcpyHostToDevice));
+  const Batch A{dA.ptr(), da, M}, D{dD.ptr(), dd, M}, Eb{dE.ptr(), dd, M};
+  // (1) ratio of the diagonal (k_diag_ratio) BEFORE the matrices are overwritten by the tridiagonalisation
+  hipLaunchKernelGGL((k_diag_ratio<NL>), dim3(M), dim3(DR_T), 0, 0, A, dratio.ptr(), (size_t)0);
+  // (2) Householder tridiagonalisation and lambda_min
+  hipLaunchKernelGGL((k_tridiag<NL, 256>), dim3(M), dim3(256), 0, 0, A, D, Eb, (const int *)dids);
+  HIP_CHECK(hipDeviceSynchronize());
+  Host<NL> hD((size_t)n * M + 1), hE((size_t)n * M + 1);
+  dD.down(hD);
+  dE.down(hE);
+  hipLaunchKernelGGL((k_tridiag_min<NL>), dim3(cdiv(M, EIG_T)), dim3(EIG_T), 0, 0, D, Eb, dF, dF + (size_t)n * M + 1, dlam.ptr());
+  // (3) the two-level reductions of Solver::reduce_to
+  mw::CPtr lp = dlam.ptr(), rp = dratio.ptr();
+  auto ldl = [=] __device__(size_t i) { return mw::load<NL>(lp, i); };
+  auto ldr = [=] __device__(size_t i) { return mw::load<NL>(rp, i); };
+  const unsigned g = std::min<unsigned>(cdiv((size_t)M, WG), 512);
+  mw::CPtr redp = dred.ptr();
+  auto ld2 = [=] __device__(size_t i) { return mw::load<NL>(redp, i); };
+  hipLaunchKernelGGL((k_reduce<NL, RED_MIN, decltype(ldl)>), dim3(g), dim3(WG), 0, 0, (size_t)M, ldl, dred.ptr());
+  hipLaunchKernelGGL((k_reduce<NL, RED_MIN, decltype(ld2)>), dim3(1), dim3(WG), 0, 0, (size_t)g, ld2, mw::Ptr{dres.p + 0, dres.n});
+  hipLaunchKernelGGL((k_reduce<NL, RED_MAX, decltype(ldr)>), dim3(g), dim3(WG), 0, 0, (size_t)M, ldr, dred.ptr());
+  hipLaunchKernelGGL((k_reduce<NL, RED_MAX, decltype(ld2)>), dim3(1), dim3(WG), 0, 0, (size_t)g, ld2, mw::Ptr{dres.p + 1, dres.n});
+  HIP_CHECK(hipDeviceSynchronize());
+  Host<NL> hlam(M), hres(8), hratio(M);
+  dlam.down(hlam);
+  dres.down(hres);
+  dratio.down(hratio);
+  // records: D and E of matrix 0, every lambda_min, every ratio, the two reductions
+  for(int i = 0; i < n; ++i)
+    push<NL>(out, mw::load<NL>(hD.ptr(), i));
+  for(int i = 1; i < n; ++i)
+    push<NL>(out, mw::load<NL>(hE.ptr(), i));
+  for(int q = 0; q < M; ++q)
+    push<NL>(out, mw::load<NL>(hlam.ptr(), q));
+  for(int q = 0; q < M; ++q)
+    push<NL>(out, mw::load<NL>(hratio.ptr(), q));
+  push<NL>(out, mw::load<NL>(hres.ptr(), 0));
+  push<NL>(out, mw::load<NL>(hres.ptr(), 1));
+  // the reductions against the host's own minimum / maximum of the downloaded arrays: bit for bit
+  Mw<NL> mn = mw::load<NL>(hlam.ptr(), 0), mx = mw::load<NL>(hratio.ptr(), 0);
+  for(int q = 1; q < M; ++q)
+    {
+      mn = mw::min(mn, mw::load<NL>(hlam.ptr(), q));
+      mx = mw::max(mx, mw::load<NL>(hratio.ptr(), q));
+    }
+  const bool okmin = mw::cmp(mn, mw::load<NL>(hres.ptr(), 0)) == 0, okmax = mw::cmp(mx, mw::load<NL>(hres.ptr(), 1)) == 0;
+  std::printf("NL=%d: k_reduce<RED_MIN> %s the host minimum of the %d lambda_min; k_reduce<RED_MAX> %s the host maximum of the ratios\n", NL,
+              okmin ? "==" : "!=", M, okmax ? "==" : "!=");
+  (void)hipFree(da);
+  (void)hipFree(dd);
+  (void)hipFree(dids);
+  (void)hipFree(dF);
+  return out;
+}
+
+int main()
+{
+  const int M = 600, n = 20;
+  std::vector<Entry> ent((size_t)M * n * n);
+  for(auto &x : ent)
+    {
+      x.mant = lcg();
+      x.e = (int)(lcg() % 5) - 2;
+      x.neg = lcg() & 1;
+    }
+  const Results a = run<PROBE_A>(ent, M, n), b = run<PROBE_B>(ent, M, n);
+  auto worst = [&](size_t lo, size_t hi) {
+    double w = -1e9;
+    for(size_t i = lo; i < hi; ++i)
+      w = std::max(w, log2_rel(a, b, i));
+    return w;
+  };
+  size_t o = 0;
+  std::printf("widths %d and %d limbs on the same %d matrices of order %d: worst log2 relative difference\n", PROBE_A, PROBE_B, M, n);
+  std::printf("  k_tridiag D of matrix 0      %8.1f\n", worst(o, o + n));
+  o += n;
+  std::printf("  k_tridiag E of matrix 0      %8.1f\n", worst(o, o + n - 1));
+  o += n - 1;
+  std::printf("  k_tridiag_min, all matrices  %8.1f\n", worst(o, o + M));
+  o += M;
+  std::printf("  k_diag_ratio, all matrices   %8.1f\n", worst(o, o + M));
+  o += M;
+  std::printf("  min of lambda_min (k_reduce) %8.1f\n", worst(o, o + 1));
+  std::printf("  max of ratios (k_reduce)     %8.1f\n", worst(o + 1, o + 2));
+  return 0;
+}

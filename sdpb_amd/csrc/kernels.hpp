@@ -4002,7 +4002,7 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NPAIR * 4 + 64];
   uint64_t cc[4][2 * M3 - 1];
   uint32_t hh[4][2 * M3 - 1];
-  uint64_t c3[4]; // LAZY: what the top column has been carried out of
+  uint64_t dd[4][2 * M3 - 1]; // LAZY: the high words taken out of the columns (weight 2^32 of their column)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK2_NO_GLDS)
   constexpr bool DIRECT = true;
 #else
@@ -4155,12 +4155,22 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   else                                                                                                                                     \
     FX3_MAC_ONE(0, va.x, va.y, vb.x, vb.y);
     // wait for the set (wa, wb) that is in flight, then issue the reads of (ra, rb)
+#ifdef SDPB_SYRK3_EXPERIMENT_HALF_LDS
+    // TIMING EXPERIMENT ONLY (wrong results): the pieces of the second operand are not read -- what the kernel would cost
+    // with half of its LDS reads (profiles/r06_syrk_lds_experiment.txt)
+#define FX3_NEXT(wa, wb, ra, rb, O0, O1)                                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read2_b64 %2, %4 offset0:" #O0 " offset1:" #O1                                                  \
+               : "+v"(wa), "+v"(wb), "=&v"(ra), "+v"(rb)                                                                                   \
+               : "v"(xa), "v"(xb)                                                                                                          \
+               : "memory")
+#else
 #define FX3_NEXT(wa, wb, ra, rb, O0, O1)                                                                                                   \
   asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read2_b64 %2, %4 offset0:" #O0 " offset1:" #O1 "\n\tds_read2_b64 %3, %5 offset0:" #O0            \
                " offset1:" #O1                                                                                                             \
                : "+v"(wa), "+v"(wb), "=&v"(ra), "=&v"(rb)                                                                                  \
                : "v"(xa), "v"(xb)                                                                                                          \
                : "memory")
+#endif
     u32x4 a0, b0, a1, b1;
     {
       const uint32_t xa = la, xb = lb;
@@ -4259,21 +4269,33 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
           }
 #pragma unroll
       for(int o = 0; o < 4; ++o)
-        c3[o] = 0;
-      // LAZY: column k of an output absorbs products < 2^56 (two of them per row in the middle column): after 64 rows it
-      // is < 2^63 and is carried into the next one, the top column into c3
-      auto carry_columns = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for(int k = 0; k < 2 * M3 - 1; ++k)
+          dd[o][k] = 0;
+      // LAZY: column k of an output absorbs products < 2^56, two of them per row in the middle column.  Nothing is carried
+      // from column to column during the sweep: the HIGH WORD of a column is moved to a second sum of the same column (an
+      // add, an add-with-carry and a move per column: no 64-bit shifts, no masks) -- the middle column every 64 rows (it is
+      // < 2^32 + 64 * 2 * 2^56 < 2^64 by then), the outer ones every 128 rows.  (First version of the round: carries from
+      // column to column every 64 rows, 15 instructions per output with three 64-bit shifts; profiles/r06_syrk_light_carry.txt)
+      auto carry_columns = [&](bool all) __attribute__((always_inline)) {
         if constexpr(LAZY)
           {
 #pragma unroll
             for(int o = 0; o < 4; ++o)
               {
-                cc[o][1] += cc[o][0] >> T5_LB;
-                cc[o][0] &= T5_MASK;
-                cc[o][2] += cc[o][1] >> T5_LB;
-                cc[o][1] &= T5_MASK;
-                c3[o] += cc[o][2] >> T5_LB;
-                cc[o][2] &= T5_MASK;
+                dd[o][1] += cc[o][1] >> 32;
+                cc[o][1] &= 0xffffffffull;
+              }
+            if(all)
+              {
+#pragma unroll
+                for(int o = 0; o < 4; ++o)
+                  {
+                    dd[o][0] += cc[o][0] >> 32;
+                    cc[o][0] &= 0xffffffffull;
+                    dd[o][2] += cc[o][2] >> 32;
+                    cc[o][2] &= 0xffffffffull;
+                  }
               }
           }
       };
@@ -4286,18 +4308,19 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
       // the same registers from block to block
       auto sweep = [&](auto mask_c) __attribute__((always_inline)) {
         int buf = 0;
+        unsigned pass = 0;
         for(unsigned r0 = row_begin; r0 < row_end; r0 += RBG)
           {
             // (after the last block of the sweep: a block that exists, staged and never read)
             fetch(prod, r0 + RBG < row_end ? r0 + RBG : row_begin, buf ^ 1);
             rows(mask_c, buf, cc, hh);
-            if(LAZY && buf == 1) // every second pass
-              carry_columns();
+            ++pass;
+            if(LAZY && (pass & 1u) == 0) // every second pass
+              carry_columns((pass & 3u) == 0);
             store(buf ^ 1);
             __syncthreads();
             buf ^= 1;
           }
-        carry_columns();
       };
       switch(mask)
         {
@@ -4318,14 +4341,15 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
             g[k] = 0;
           if constexpr(LAZY)
             {
-              // c0 + c1 2^28 + c2 2^56 + c3 2^84 with c0, c1, c2 < 2^28 (carried) and c3 < 2^44: 4 words
-              const uint64_t t0 = cc[o][0] + (cc[o][1] << T5_LB);
-              const uint64_t t1 = (t0 >> 32) + (cc[o][2] << (2 * T5_LB - 32));
-              const uint64_t t2 = (t1 >> 32) + (c3[o] << (3 * T5_LB - 64));
-              g[0] = (uint32_t)t0;
-              g[1] = (uint32_t)t1;
-              g[2] = (uint32_t)t2;
-              g[3] = (uint32_t)(t2 >> 32);
+              // sum_k (c_k + d_k 2^32) 2^(28 k): below 2^124 (fewer than 2^12 rows of products < 2^112): 4 words
+              unsigned __int128 v = 0;
+#pragma unroll
+              for(int k = 0; k < 2 * M3 - 1; ++k)
+                v += ((unsigned __int128)cc[o][k] + ((unsigned __int128)dd[o][k] << 32)) << (T5_LB * k);
+              g[0] = (uint32_t)v;
+              g[1] = (uint32_t)(v >> 32);
+              g[2] = (uint32_t)(v >> 64);
+              g[3] = (uint32_t)(v >> 96);
             }
           else
           syrk_fold<M3, A3>(g, cc[o], hh[o]);
