@@ -178,8 +178,115 @@ template <int NL> Results run(const std::vector<Entry> &ent, int M, int n)
   return out;
 }
 
+// The batched Cholesky chain (Solver::blocked_cholesky: k_chol_inv_lds, k_chol_panel_solve, k_chol_syrk_down per panel) of
+// diagonally dominant SPD matrices, and P = L^-1 B by k_trsm_rlt_panel on a right-hand side of all ones.
+template <int NL> Results run_chol(const std::vector<Entry> &ent, int M, int n)
+{
+  Results out;
+  const size_t per = (size_t)n * n;
+  Host<NL> hA(per * M), hX(per * M);
+  for(int q = 0; q < M; ++q)
+    for(int i = 0; i < n; ++i)
+      for(int j = 0; j <= i; ++j)
+        {
+          const Entry &x = ent[(size_t)q * per + (size_t)i * n + j];
+          Mw<NL> v = from_bits<NL>(x.mant, i == j ? 3 : -3 - (x.e & 1), i == j ? false : x.neg);
+          mw::store<NL>(hA.ptr(), (size_t)q * per + i + (size_t)j * n, v);
+          mw::store<NL>(hA.ptr(), (size_t)q * per + j + (size_t)i * n, v);
+        }
+  for(size_t k = 0; k < per * M; ++k)
+    mw::store<NL>(hX.ptr(), k, from_bits<NL>(ent[k].mant, 1, ent[k].neg));
+  Dev<NL> dA(per * M), dLi(per * M), dinv((size_t)n * M + 1), dX(per * M);
+  dA.up(hA);
+  dX.up(hX);
+  std::vector<MatDesc> ha(M), hd(M);
+  for(int q = 0; q < M; ++q)
+    {
+      ha[q] = MatDesc{(unsigned long long)q * per, n, n, n, 0};
+      hd[q] = MatDesc{(unsigned long long)q * n, n, 1, n, 0};
+    }
+  MatDesc *da, *dd;
+  int *fail;
+  HIP_CHECK(hipMalloc(&da, M * sizeof(MatDesc)));
+  HIP_CHECK(hipMalloc(&dd, M * sizeof(MatDesc)));
+  HIP_CHECK(hipMalloc(&fail, 64 * sizeof(int)));
+  HIP_CHECK(hipMemset(fail, 0, 64 * sizeof(int)));
+  HIP_CHECK(hipMemcpy(da, ha.data(), M * sizeof(MatDesc), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(dd, hd.data(), M * sizeof(MatDesc), hipMemcpyHostToDevice));
+  const Batch A{dA.ptr(), da, M}, Li{dLi.ptr(), da, M}, invd{dinv.ptr(), dd, M}, X{dX.ptr(), da, M};
+  const int panels = (n + PB - 1) / PB;
+  for(int p = 0; p < panels; ++p)
+    {
+      hipLaunchKernelGGL((k_chol_inv_lds<NL>), dim3(M), dim3(CI_T), 0, 0, A, invd, Li, p, fail, (unsigned long long *)nullptr);
+      const int below = n - PB * (p + 1), above = PB * p, rows = below > above ? below : above;
+      if(rows > 0)
+        hipLaunchKernelGGL((k_chol_panel_solve<NL>), dim3(cdiv(rows, TR), M), dim3(WG), 0, 0, A, Li, p, 0, (unsigned long long *)nullptr);
+      if(below > 0)
+        {
+          const unsigned tiles = cdiv(below, 16);
+          hipLaunchKernelGGL((k_chol_syrk_down<NL>), dim3(tiles * (tiles + 1) / 2, M), dim3(WG), 0, 0, A, p, 0, (unsigned long long *)nullptr, 0, 0x7fffffff);
+        }
+      if(p == 0)
+        {
+          HIP_CHECK(hipDeviceSynchronize());
+          Host<NL> h0(per * M);
+          dA.down(h0);
+          for(int q = 0; q < 4; ++q) // the first diagonal block after k_chol_inv_lds alone, and what the panel solve left below it
+            for(int j = 0; j < (n < PB ? n : PB); ++j)
+              for(int i = j; i < n; ++i)
+                push<NL>(out, mw::load<NL>(h0.ptr(), (size_t)q * per + i + (size_t)j * n));
+        }
+    }
+  const mw::CPtr src(dX.p, dX.n);
+  for(int p = 0; p < panels; ++p)
+    hipLaunchKernelGGL((k_trsm_rlt_panel<NL>), dim3(cdiv(n, TR), M), dim3(WG), 0, 0, A, Li, X, src, p, (unsigned long long *)nullptr);
+  HIP_CHECK(hipDeviceSynchronize());
+  Host<NL> hL(per * M), hP(per * M);
+  dA.down(hL);
+  dX.down(hP);
+  for(int q = 0; q < M; ++q)
+    for(int j = 0; j < n; ++j)
+      for(int i = j; i < n; ++i)
+        push<NL>(out, mw::load<NL>(hL.ptr(), (size_t)q * per + i + (size_t)j * n));
+  for(size_t k = 0; k < per * M; ++k)
+    push<NL>(out, mw::load<NL>(hP.ptr(), k));
+  int hf[4];
+  HIP_CHECK(hipMemcpy(hf, fail, sizeof hf, hipMemcpyDeviceToHost));
+  std::printf("NL=%d: Cholesky failure flags %d %d\n", NL, hf[0], hf[1]);
+  (void)hipFree(da);
+  (void)hipFree(dd);
+  (void)hipFree(fail);
+  return out;
+}
+
 int main()
 {
+  {
+    const int M = 64, n = 40;
+    std::vector<Entry> ent((size_t)M * n * n);
+    for(auto &x : ent)
+      {
+        x.mant = lcg();
+        x.e = (int)(lcg() % 5) - 2;
+        x.neg = lcg() & 1;
+      }
+    const Results a = run_chol<PROBE_A>(ent, M, n), b = run_chol<PROBE_B>(ent, M, n);
+    auto worst = [&](size_t lo, size_t hi) {
+      double w = -1e9;
+      for(size_t i = lo; i < hi; ++i)
+        w = std::max(w, log2_rel(a, b, i));
+      return w;
+    };
+    const int nb = n < PB ? n : PB;
+    size_t first = 0;
+    for(int j = 0; j < nb; ++j)
+      first += (size_t)(n - j);
+    const size_t tri = (size_t)n * (n + 1) / 2;
+    std::printf("Cholesky chain, %d matrices of order %d, panels of %d: worst log2 relative difference between %d and %d limbs\n", M, n, PB, PROBE_A, PROBE_B);
+    std::printf("  after panel 0 (k_chol_inv_lds + k_chol_panel_solve), 4 matrices   %8.1f\n", worst(0, 4 * first));
+    std::printf("  the finished factors L                                           %8.1f\n", worst(4 * first, 4 * first + M * tri));
+    std::printf("  X L^-T by k_trsm_rlt_panel                                       %8.1f\n", worst(4 * first + M * tri, a.e.size()));
+  }
   const int M = 600, n = 20;
   std::vector<Entry> ent((size_t)M * n * n);
   for(auto &x : ent)

@@ -16,24 +16,47 @@ def _solver(sdp, precision, params=None):
 
 
 # ---- arithmetic: device ops vs GMP mpf (oracle), tolerance 2 ulp of the device mantissa
+def _check_arithmetic(s, o, dense, count, seed):
+    """add, sub, mul, div, sqrt of the device against GMP at four times the precision.  dense: every limb of both operands is
+    random (round 6: the 40-digit operands of the earlier rounds have 133 significant bits -- the low limbs of both are zero,
+    and tests.parity compares at 1400 bits, so above 43 limbs the old test proved 1400 bits, not 2 ulp).  Returns the worst
+    log2 relative error per operation, compared at four times the device mantissa."""
+    bits = 32 * s.limbs
+    digits = int(bits * 0.30103) + 12
+    rng = random.Random(seed)
+    worst = {}
+
+    def number():
+        if not dense:
+            return mpmath.nstr(mpmath.mpf(rng.uniform(-1, 1)) * mpmath.mpf(10) ** rng.randint(-40, 40), 40)
+        body = rng.choice("123456789") + "".join(rng.choice("0123456789") for _ in range(digits - 1))
+        return ("-" if rng.random() < 0.5 else "") + "0." + body + "e" + str(rng.randint(-40, 40))
+
+    with mpmath.workprec(4 * bits):
+        for _ in range(count):
+            sa, sb = number(), number()
+            for op in ("add", "sub", "mul", "div", "sqrt"):
+                xa = sa.lstrip("-") if op == "sqrt" else sa
+                got, want = s.op_scalar(op, xa, sb), o.scalar_op(op, xa, sb)
+                err = parity.log2_rel(got, want)
+                assert err <= -(bits - 2), (op, err, sa[:30], sb[:30])
+                worst[op] = max(worst.get(op, float("-inf")), err)
+    return worst
+
+
 @pytest.mark.parametrize("precision", [128, 256, 512, 768, 1024, 1280, 1536, 2048])
 def test_device_arithmetic_matches_mpf(precision):
     from oracle.oracle import Oracle
     sdp, _, _, _ = parity.load_case("1d")
     s = _solver(sdp, precision)
     # oracle computes at a much higher precision: exact reference values
-    o = Oracle(sdp, 4 * precision + 256)
-    bits = 32 * s.limbs
-    rng = random.Random(precision)
-    for _ in range(40):
-        a = mpmath.mpf(rng.uniform(-1, 1)) * mpmath.mpf(10) ** rng.randint(-40, 40)
-        b = mpmath.mpf(rng.uniform(-1, 1)) * mpmath.mpf(10) ** rng.randint(-40, 40)
-        sa, sb = mpmath.nstr(a, 40), mpmath.nstr(b, 40)
-        for op in ("add", "sub", "mul", "div", "sqrt"):
-            xa = sa.lstrip("-") if op == "sqrt" else sa
-            got, want = s.op_scalar(op, xa, sb), o.scalar_op(op, xa, sb)
-            assert parity.log2_rel(got, want) <= -(bits - 2), (op, sa, sb)
+    o = Oracle(sdp, 4 * 32 * s.limbs + 256)
+    _check_arithmetic(s, o, dense=False, count=40, seed=precision)
+    worst = _check_arithmetic(s, o, dense=True, count=16, seed=precision + 1)
+    # the comparison really sees the last limb: a dense result cannot agree with the exact value beyond its own mantissa
+    assert all(-(32 * s.limbs + 40) < w for w in worst.values()), worst
     s.close()
+    o.close()
 
 
 # ---- the syrk_Q stage as an operator: calculate_matrix_square.test.cxx recipe + saturated columns

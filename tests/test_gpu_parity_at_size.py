@@ -65,6 +65,40 @@ def test_gpu_matches_live_oracle_beyond_one_panel(name, c, iters):
     o.close()
 
 
+@pytest.mark.parametrize("precision", [400, 768, 1024])
+def test_small_feasible_run_to_optimality_matches_the_live_oracle(precision):
+    """The strictly feasible family (sdpb_amd/synthetic.py) at the other compiled widths, followed against the LIVE oracle until
+    both stop with 'found primal-dual optimal solution' in the same iteration: the end game of a convergent run -- step
+    lengths gamma / (1 - beta) from a spectrum that collapses onto one point (k_tridiag_min's shifted, multiplicity-aware
+    Newton on the 16-, 26- and 34-limb ladders), block condition numbers past 2^(p/2) -- on the Toom-4 x Karatsuba syrk and
+    the float triangular solves that 512 bits no longer use.  N = 40: two panels of Cholesky(Q).  Bars: 2^-(p/2), relaxed to
+    cond 2^-(p-16) only where the iteration's own condition numbers pass 2^(p/2-16) (parity.conditioned_tol_bits)."""
+    from oracle.oracle import Oracle
+    from sdpb_amd.synthetic import make_lazy
+    sdp, src = make_lazy([2] * 4 + [1] * 8, [12] * 12, 40, precision, 9, feasible=True)
+    s = SDPSolver(sdp, precision, parity.DEFAULT_PARAMS, lib_path=libs.product_lib(), block_source=src)
+    o = Oracle(sdp, precision, parity.DEFAULT_PARAMS, param_prec=0, block_source=src)
+    worst, it, relaxed = float("-inf"), 0, 0
+    while True:
+        ts, to = s.iterate(), o.iterate()
+        assert ts == to, (it + 1, s.terminate_reason, o.terminate_reason)
+        if ts:
+            break
+        it += 1
+        rec = o.scalars()
+        tol = parity.conditioned_tol_bits(rec, precision, precision // 2)
+        relaxed += tol < precision // 2
+        bad, w = parity.compare_iteration(s.scalars(), rec, tol_bits=tol)
+        worst = max(worst, w)
+        assert not bad, (it, bad, tol)
+        assert it < 400
+    assert s.terminate_reason == o.terminate_reason == "found primal-dual optimal solution"
+    print(f"feasible J={sdp.J} N={sdp.N} p={precision}: {it} iterations to optimality, worst log2 rel diff {worst:.1f}, "
+          f"{relaxed} iterations on the conditioned bar")
+    s.close()
+    o.close()
+
+
 FIXTURES = sorted(f for f in (os.listdir(SYN) if os.path.isdir(SYN) else []) if f.endswith(".json") and f != "gate_thresholds.json")
 
 
