@@ -178,6 +178,99 @@ template <int NL> Results run(const std::vector<Entry> &ent, int M, int n)
   return out;
 }
 
+// Ingredients of k_chol_inv_lds one at a time, device against the HOST's evaluation of the same mw:: functions (the host
+// arithmetic is exact against GMP at every width: tests/shim, profiles/r06_*): (1) the wavefront's reciprocal square root
+// wv::rsqrt (above 58 limbs: the one-lane ladder on a broadcast copy), (2) an mw::Acc sum of products with mixed signs and
+// exponents, (3) the limb-major LDS image ci_st -> ci_ld.
+template <int NL> __global__ void __launch_bounds__(64) k_ingredients(mw::CPtr in, int K, mw::Ptr out)
+{
+  const int t = threadIdx.x;
+  __shared__ uint32_t img[(NL + CI_PLANES_EXTRA) * CI_NPK];
+  // (1) lane 5 owns the argument
+  Mw<NL> a = mw::zero<NL>();
+  if(t == 5)
+    a = mw::load<NL>(in, 0);
+  const Mw<NL> r = mw::wv::rsqrt<NL>(a, 5);
+  if(t == 9)
+    mw::store<NL>(out, 0, r);
+  const Mw<NL> sq = mw::wv::sqrt<NL>(a, 5);
+  if(t == 11)
+    mw::store<NL>(out, 1, sq);
+  const Mw<NL> rc = mw::wv::rcp<NL>(a, 5);
+  if(t == 13)
+    mw::store<NL>(out, 2, rc);
+  // (2) every lane the same sum (lane 17 stores)
+  mw::Acc<NL> acc = mw::acc_zero<NL>();
+  for(int k = 0; k < K; ++k)
+    {
+      const Mw<NL> x = mw::load<NL>(in, 1 + 2 * k), y = mw::load<NL>(in, 2 + 2 * k);
+      if(k % 3 == 2)
+        mw::acc_fms(acc, x, y);
+      else
+        mw::acc_fma(acc, x, y);
+    }
+  const Mw<NL> sum = mw::acc_result(acc);
+  if(t == 17)
+    mw::store<NL>(out, 3, sum);
+  // (3) LDS image round trip of the first CI_NPK inputs
+  for(int i = t; i < CI_NPK && i < 2 * K; i += 64)
+    ci_st<NL>(img, i, mw::load<NL>(in, 1 + i));
+  __syncthreads();
+  for(int i = t; i < CI_NPK && i < 2 * K; i += 64)
+    mw::store<NL>(out, 4 + i, ci_ld<NL>(img, i));
+}
+template <int NL> void run_ingredients()
+{
+  const int K = 40;
+  Host<NL> hin(1 + 2 * K), hout(4 + 2 * K);
+  auto dense = [&](int e, bool neg) {
+    Mw<NL> v;
+    for(int i = 0; i < NL; ++i)
+      v.m[i] = (uint32_t)lcg();
+    v.m[NL - 1] |= 0x80000000u;
+    v.e = e;
+    v.neg = neg ? 1u : 0u;
+    return v;
+  };
+  mw::store<NL>(hin.ptr(), 0, dense(7, false));
+  for(int k = 0; k < 2 * K; ++k)
+    mw::store<NL>(hin.ptr(), 1 + k, dense((int)(lcg() % 200) - 100, lcg() & 1));
+  Dev<NL> din(1 + 2 * K), dout(4 + 2 * K);
+  din.up(hin);
+  hipLaunchKernelGGL((k_ingredients<NL>), dim3(1), dim3(64), 0, 0, mw::CPtr(din.p, din.n), K, dout.ptr());
+  HIP_CHECK(hipDeviceSynchronize());
+  dout.down(hout);
+  const Mw<NL> a = mw::load<NL>(hin.ptr(), 0);
+  mw::Acc<NL> acc = mw::acc_zero<NL>();
+  for(int k = 0; k < K; ++k)
+    {
+      const Mw<NL> x = mw::load<NL>(hin.ptr(), 1 + 2 * k), y = mw::load<NL>(hin.ptr(), 2 + 2 * k);
+      if(k % 3 == 2)
+        mw::acc_fms(acc, x, y);
+      else
+        mw::acc_fma(acc, x, y);
+    }
+  Results dev, host;
+  push<NL>(dev, mw::load<NL>(hout.ptr(), 0));
+  push<NL>(host, mw::rsqrt<NL>(a));
+  push<NL>(dev, mw::load<NL>(hout.ptr(), 1));
+  push<NL>(host, mw::sqrt<NL>(a));
+  push<NL>(dev, mw::load<NL>(hout.ptr(), 2));
+  push<NL>(host, mw::rcp<NL>(a));
+  push<NL>(dev, mw::load<NL>(hout.ptr(), 3));
+  push<NL>(host, mw::acc_result(acc));
+  double img = -1e9;
+  for(int i = 0; i < CI_NPK && i < 2 * K; ++i)
+    {
+      Results x, y;
+      push<NL>(x, mw::load<NL>(hout.ptr(), 4 + i));
+      push<NL>(y, mw::load<NL>(hin.ptr(), 1 + i));
+      img = std::max(img, log2_rel(x, y, 0));
+    }
+  std::printf("NL=%d ingredients, device against host (log2 relative difference; %d = identical): wv::rsqrt %.1f  wv::sqrt %.1f  wv::rcp %.1f  Acc sum of %d products %.1f  LDS image round trip %.1f\n",
+              NL, -32 * NL, log2_rel(dev, host, 0), log2_rel(dev, host, 1), log2_rel(dev, host, 2), K, log2_rel(dev, host, 3), img);
+}
+
 // The batched Cholesky chain (Solver::blocked_cholesky: k_chol_inv_lds, k_chol_panel_solve, k_chol_syrk_down per panel) of
 // diagonally dominant SPD matrices, and P = L^-1 B by k_trsm_rlt_panel on a right-hand side of all ones.
 template <int NL> Results run_chol(const std::vector<Entry> &ent, int M, int n)
@@ -261,6 +354,8 @@ template <int NL> Results run_chol(const std::vector<Entry> &ent, int M, int n)
 
 int main()
 {
+  run_ingredients<PROBE_A>();
+  run_ingredients<PROBE_B>();
   {
     const int M = 64, n = 40;
     std::vector<Entry> ent((size_t)M * n * n);

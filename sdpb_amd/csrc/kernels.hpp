@@ -3953,6 +3953,9 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK_WAVES)
 #ifndef SDPB_SYRK3_WAVES
 #define SDPB_SYRK3_WAVES 3
 #endif
+#ifndef SDPB_SYRK3_NBUF
+#define SDPB_SYRK3_NBUF 2 // staging buffers of the lazy-carry mode; 3 (requests two passes ahead) was measured: no gain, see below
+#endif
 template <int FX, int RBG>
 __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   k_syrk_fx3(const uint32_t *__restrict__ fx_in, size_t fx_stride, unsigned nrows, int N, uint32_t *acc, size_t acc_stride,
@@ -3997,9 +4000,20 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
   // quadrant (p, q): rows i0 + 16 p of the output against columns j0 + 16 q; workgroup-uniform
   const bool half_i = ti * 32 + 16 < N, half_j = tj * 32 + 16 < N;
   const int mask = 1 | (half_i ? 2 : 0) | ((half_j && tj < ti) ? 4 : 0) | ((half_i && half_j) ? 8 : 0); // bit p + 2 q
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDPB_SYRK2_NO_GLDS)
+  // -DSDPB_SYRK3_NBUF=3 (LAZY): three staging buffers, the rows of pass i + 2 requested while pass i multiplies.  Measured and
+  // NOT the default (profiles/r06_syrk_prefetch_depth.txt): the kernel without any fetch after the first pass of a sweep
+  // (wrong results, timing only: -DSDPB_SYRK3_EXPERIMENT_NO_FETCH) takes 74.3 instead of 82.2 ms for the whole syrk_G, which
+  // looked like passes waiting for rows that miss the XCD's L2 -- but requesting the rows a pass earlier changes nothing
+  // (81.9 against 80.9 ms, bit-exact either way): the 8 ms are the cost of the requests themselves, not of waiting for them.
+  constexpr int NBUF = LAZY ? SDPB_SYRK3_NBUF : 2;
+#else
+  constexpr int NBUF = 2;
+#endif
+  static_assert(NBUF == 2 || NBUF == 3, "double or triple buffering");
   // (+ 64 words: the prefetching row loop reads one row past the pass it is in)
-  __shared__ __attribute__((aligned(16))) uint32_t sa[2 * NPAIR * 4 + 64];
-  __shared__ __attribute__((aligned(16))) uint32_t sb[2 * NPAIR * 4 + 64];
+  __shared__ __attribute__((aligned(16))) uint32_t sa[NBUF * NPAIR * 4 + 64];
+  __shared__ __attribute__((aligned(16))) uint32_t sb[NBUF * NPAIR * 4 + 64];
   uint64_t cc[4][2 * M3 - 1];
   uint32_t hh[4][2 * M3 - 1];
   uint64_t dd[4][2 * M3 - 1]; // LAZY: the high words taken out of the columns (weight 2^32 of their column)
@@ -4300,10 +4314,24 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
           }
       };
       if(prod > prod_begin)
-        __syncthreads(); // every wavefront has left the last pass of the previous sweep
+        __syncthreads(); // every wavefront has left the last pass of the previous sweep (and what it over-fetched has landed)
+      // the barrier that ends a pass: the rows of the NEXT pass have landed in LDS; with three buffers the requests of
+      // the pass after it (2 GL per lane, the youngest) may still be in flight
+      auto pass_barrier = [&]() __attribute__((always_inline)) {
+        if constexpr(NBUF == 3)
+          {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * GL) : "memory");
+#endif
+          }
+        else
+          __syncthreads();
+      };
       fetch(prod, row_begin, 0);
+      if constexpr(NBUF == 3)
+        fetch(prod, row_begin + RBG < row_end ? row_begin + RBG : row_begin, 1);
       store(0);
-      __syncthreads();
+      pass_barrier();
       // the row blocks of the sweep; the quadrant mask is chosen outside the loop, so that the accumulators stay in
       // the same registers from block to block
       auto sweep = [&](auto mask_c) __attribute__((always_inline)) {
@@ -4312,14 +4340,30 @@ __global__ void __launch_bounds__(WG, SDPB_SYRK3_WAVES)
         for(unsigned r0 = row_begin; r0 < row_end; r0 += RBG)
           {
             // (after the last block of the sweep: a block that exists, staged and never read)
-            fetch(prod, r0 + RBG < row_end ? r0 + RBG : row_begin, buf ^ 1);
+#ifdef SDPB_SYRK3_EXPERIMENT_NO_FETCH
+            if(r0 == row_begin) // TIMING EXPERIMENT ONLY (wrong results): what the kernel costs when no pass waits for its rows
+#endif
+            {
+              if constexpr(NBUF == 3)
+                fetch(prod, r0 + 2 * RBG < row_end ? r0 + 2 * RBG : row_begin, buf >= 1 ? buf - 1 : 2);
+              else
+                fetch(prod, r0 + RBG < row_end ? r0 + RBG : row_begin, buf ^ 1);
+            }
             rows(mask_c, buf, cc, hh);
             ++pass;
             if(LAZY && (pass & 1u) == 0) // every second pass
               carry_columns((pass & 3u) == 0);
-            store(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
+            if constexpr(NBUF == 3)
+              {
+                pass_barrier();
+                buf = buf == 2 ? 0 : buf + 1;
+              }
+            else
+              {
+                store(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+              }
           }
       };
       switch(mask)
