@@ -1024,6 +1024,11 @@ __global__ void __launch_bounds__(WG) k_td_image_L(Batch L, Batch Li, const int 
 #ifndef SDPB_TD_KC
 #define SDPB_TD_KC 4 // k-slices of the right operand's image per LDS pass of the tile dot products
 #endif
+#ifndef SDPB_TD_PREFETCH
+#define SDPB_TD_PREFETCH 0 // 1: the next slice of the right operand requested before the products of this one.  Measured and
+                           // left off: Q.solve 29.6 against 27.5 ms on C4 (three more 16-byte registers per lane spill at
+                           // the 128 VGPRs that four workgroups per CU allow; profiles/r06r_variants.txt)
+#endif
 #ifndef SDPB_TD_TRSM_WG_PER_CU
 #define SDPB_TD_TRSM_WG_PER_CU 4 // measured on C4 (profiles/r06b_variants.txt): 2 / 3 / 4 workgroups per CU (208 / 168 / 128 VGPRs) 36.9 / 32.6 / 31.2 ms
 #endif
@@ -1035,8 +1040,40 @@ MW_HD void td_tile_product(td::Cols<W> &g, const uint32_t *sX, uint32_t *sL, con
   constexpr int SL_WORDS = KC * PB * W;
   static_assert(SL_WORDS % 4 == 0, "16-byte moves of a slice");
   td::cols_zero<W>(g);
+#if SDPB_TD_PREFETCH
+  // the slice of the NEXT pass is requested before the products of this one and written to LDS when they are done: the
+  // round trip to L2 (every workgroup of a block streams the same tile image) is no longer exposed at every barrier
+  constexpr int NQ = (SL_WORDS / 4 + WG - 1) / WG;
+  td::Quad pre[NQ];
+  auto request = [&](int c) {
+    const td::Quad *gsrc = reinterpret_cast<const td::Quad *>(tile_img + (size_t)c * PB * W);
+#pragma unroll
+    for(int u = 0; u < NQ; ++u)
+      {
+        const int f = threadIdx.x + u * WG;
+        if(f < SL_WORDS / 4)
+          pre[u] = gsrc[f];
+      }
+  };
+  request(0);
+#endif
   for(int c = 0; c < PB; c += KC)
     {
+#if SDPB_TD_PREFETCH
+      {
+        td::Quad *dst = reinterpret_cast<td::Quad *>(sL);
+#pragma unroll
+        for(int u = 0; u < NQ; ++u)
+          {
+            const int f = threadIdx.x + u * WG;
+            if(f < SL_WORDS / 4)
+              dst[f] = pre[u];
+          }
+      }
+      __syncthreads();
+      if(c + KC < PB) // (workgroup-uniform: `terms` differs between the wavefronts of a diagonal tile, the slice is everybody's)
+        request(c + KC);
+#else
       {
         const td::Quad *gsrc = reinterpret_cast<const td::Quad *>(tile_img + (size_t)c * PB * W);
         td::Quad *dst = reinterpret_cast<td::Quad *>(sL);
@@ -1044,6 +1081,7 @@ MW_HD void td_tile_product(td::Cols<W> &g, const uint32_t *sX, uint32_t *sL, con
           dst[f] = gsrc[f];
       }
       __syncthreads();
+#endif
       if(ok)
         {
 #pragma unroll 1
