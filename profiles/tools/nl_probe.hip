@@ -354,8 +354,10 @@ template <int NL> Results run_chol(const std::vector<Entry> &ent, int M, int n)
 
 int main()
 {
+#ifdef PROBE_INGREDIENTS
   run_ingredients<PROBE_A>();
   run_ingredients<PROBE_B>();
+#endif
   {
     const int M = 64, n = 40;
     std::vector<Entry> ent((size_t)M * n * n);
@@ -379,6 +381,29 @@ int main()
     const size_t tri = (size_t)n * (n + 1) / 2;
     std::printf("Cholesky chain, %d matrices of order %d, panels of %d: worst log2 relative difference between %d and %d limbs\n", M, n, PB, PROBE_A, PROBE_B);
     std::printf("  after panel 0 (k_chol_inv_lds + k_chol_panel_solve), 4 matrices   %8.1f\n", worst(0, 4 * first));
+    {
+      // the same entries split: the diagonal block (k_chol_inv_lds alone), column by column, and the rows below it (k_chol_panel_solve)
+      double wd = -1e9, wb = -1e9;
+      size_t o = 0;
+      std::printf("  diagonal block of matrix 0, worst per column:");
+      for(int j = 0; j < nb; ++j)
+        {
+          double wc = -1e9;
+          for(int i = j; i < n; ++i, ++o)
+            {
+              const double l = log2_rel(a, b, o);
+              if(i < nb)
+                {
+                  wd = std::max(wd, l);
+                  wc = std::max(wc, l);
+                }
+              else
+                wb = std::max(wb, l);
+            }
+          std::printf(" %.0f", wc);
+        }
+      std::printf("\n  matrix 0: diagonal block (k_chol_inv_lds) %8.1f   rows below it (k_chol_panel_solve) %8.1f\n", wd, wb);
+    }
     std::printf("  the finished factors L                                           %8.1f\n", worst(4 * first, 4 * first + M * tri));
     std::printf("  X L^-T by k_trsm_rlt_panel                                       %8.1f\n", worst(4 * first + M * tri, a.e.size()));
   }
