@@ -12,6 +12,8 @@ data.  tests/test_gpu_parity.py::test_gpu_matches_oracle_fixture_at_full_size re
     python tests/golden/synthetic/make_synthetic_golden.py C3 4
     python tests/golden/synthetic/make_synthetic_golden.py C3 term            # until SDP_Solver::run stops
     python tests/golden/synthetic/make_synthetic_golden.py C4 term 0.25 C4_x0.25_to_termination
+    python tests/golden/synthetic/make_synthetic_golden.py C4f term 0.25 C4f_x0.25_to_termination   # the strictly feasible
+                                  # family (sdpb_amd/synthetic.py): 159 iterations to 'found primal-dual optimal solution'
 
 With `term` the oracle runs until its loop ends (run.cxx:380-467: a terminate reason from
 compute_feasible_and_termination.cxx or step.cxx:145-153) and the fixture also records

@@ -99,6 +99,45 @@ def test_small_feasible_run_to_optimality_matches_the_live_oracle(precision):
     o.close()
 
 
+def test_full_size_feasible_run_reaches_optimality_on_the_device():
+    """C4's full shape (J = 600, N = 1000, P_tot = 40 000, 512 bits) from the strictly feasible family, run on the device alone
+    until SDP_Solver::run stops: no oracle record exists at this size (an oracle iteration takes minutes), so the checks are
+    the size-independent ones the problem offers -- the run ends with 'found primal-dual optimal solution'
+    (compute_feasible_and_termination.cxx:16-64) in about as many iterations as the quarter-size fixture the oracle followed
+    (160), primal and dual objective agree to the duality-gap threshold, both errors are below theirs, mu fell by more than
+    60 orders of magnitude, every step length stayed in (0, 1], and a fresh solver repeats the first dozen iterations bit for
+    bit."""
+    c = _shape("C4f")
+    assert c.get("feasible") and c["N"] == 1000 and len(c["dims"]) == 600
+    keys = ("mu", "P-obj", "D-obj", "P-step", "D-step", "Q_cond_number")
+    sdp, s, _ = _pair(c, oracle=False)
+    it, mu0, twelfth = 0, None, None
+    while not s.iterate():
+        it += 1
+        sc = s.scalars()
+        mu0 = mpmath.mpf(sc["mu"]) if mu0 is None else mu0
+        assert 0 < mpmath.mpf(sc["P-step"]) <= 1 and 0 < mpmath.mpf(sc["D-step"]) <= 1, (it, sc["P-step"], sc["D-step"])
+        if it == 12:
+            twelfth = [sc[k] for k in keys]
+        assert it < 400
+    assert s.terminate_reason == "found primal-dual optimal solution", s.terminate_reason
+    assert 120 <= it <= 220, it
+    po, do = mpmath.mpf(s.scalar("primalObjective")), mpmath.mpf(s.scalar("dualObjective"))
+    gap = abs(po - do) / max(abs(po) + abs(do), 1)
+    sc = s.scalars()
+    assert gap < mpmath.mpf("1e-30") and abs(mpmath.mpf(sc["P-err"])) < mpmath.mpf("1e-30") and abs(mpmath.mpf(sc["D-err"])) < mpmath.mpf("1e-30")
+    assert mpmath.mpf(sc["mu"]) < mu0 * mpmath.mpf("1e-60")
+    print(f"C4f full size: {it} iterations to optimality, primal objective {mpmath.nstr(po, 20)}, relative gap {mpmath.nstr(gap, 3)}, "
+          f"mu {mpmath.nstr(mu0, 3)} -> {mpmath.nstr(mpmath.mpf(sc['mu']), 3)}, "
+          f"block condition 2^{float(mpmath.log(mpmath.mpf(sc['max_block_cond_number']), 2)):.0f}")
+    s.close()
+    sdp, s, _ = _pair(c, oracle=False)
+    for _ in range(12):
+        assert not s.iterate()
+    assert [s.scalars()[k] for k in keys] == twelfth
+    s.close()
+
+
 FIXTURES = sorted(f for f in (os.listdir(SYN) if os.path.isdir(SYN) else []) if f.endswith(".json") and f != "gate_thresholds.json")
 
 
