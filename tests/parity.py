@@ -71,6 +71,28 @@ def compare_iteration(got: dict, want: dict, tol_bits: int = 99, skip_err_below_
     return bad, worst
 
 
+def check_int_syrk_extremes(s, rows, cols):
+    """The exact integer syrk on the inputs that load its carry-free column sums the most: EVERY entry at the largest
+    magnitude the image holds (all limbs of all pieces at their maximum), one full sweep of `rows` rows (the caller forces
+    one row split), columns with constant sign +, -, and rows of alternating sign.  Random inputs sit at a quarter of the bound
+    the kernel's carry schedule is derived from (k_syrk_fx3, LAZY: a 64-bit column absorbs 64 rows of products < 2^56), so
+    only these prove the schedule.  Expected values are plain Python integers."""
+    fb = s.fx_frac_bits
+    big = 2 ** fb - 1
+    patterns = [lambda r, c: big,
+                lambda r, c: big if c % 2 == 0 else -big,
+                lambda r, c: big if (r + c) % 2 == 0 else -big,
+                lambda r, c: -big if c % 3 == 0 else big - (c + 1) * (2 ** (fb // 2))]
+    for k, f in enumerate(patterns):
+        cols_v = [[f(r, c) for r in range(rows)] for c in range(cols)]
+        vals = [cols_v[c][r] for c in range(cols) for r in range(rows)]   # column-major rows x cols
+        got = s.op_int_syrk(rows, cols, vals)
+        for j in range(cols):
+            for i in range(j, cols):
+                want = sum(a * b for a, b in zip(cols_v[i], cols_v[j]))
+                assert got[i + j * cols] == want, (k, i, j)
+
+
 def conditioned_tol_bits(rec: dict, precision: int, tol_bits: int, guard_bits: int = 16) -> int:
     """The bar an iteration can be held to when its linear algebra is ill-conditioned: two p-bit computations of the same
     iteration that round in different orders (GMP's mpf products truncate, the device rounds to nearest; sums are taken

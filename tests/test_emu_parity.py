@@ -250,6 +250,17 @@ def test_documented_build_without_the_karatsuba_level_keeps_working():
     o.close()
 
 
+@pytest.mark.parametrize("precision,rows", [(512, 2560), (768, 300), (1024, 300)])
+def test_emulated_int_syrk_with_every_entry_at_the_largest_magnitude_over_one_sweep(precision, rows, monkeypatch):
+    """CPU twin of the GPU test: parity.check_int_syrk_extremes on the emulation build (the lazy-carry mode adds into plain
+    64-bit sums here as on the device, so an overflow of the carry schedule would wrap the same way)."""
+    monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", "1")
+    sdp, _, _, _ = parity.load_case("1d")
+    s = SDPSolver(sdp, precision, lib_path=libs.emu_lib())
+    parity.check_int_syrk_extremes(s, rows, 37)
+    s.close()
+
+
 def test_documented_build_without_toom5_keeps_working():
     """-DSDPB_SYRK_NO_TOOM5K (Toom-4 x Karatsuba with carried 96-bit column sums, the kernel of
     rounds 4-5 and its 487-bit image at 512 bits) stays a working option: exact product over several 32-column tiles and every

@@ -69,6 +69,17 @@ def test_syrk_Q_stage_and_saturated_columns(precision):
     s.close()
 
 
+@pytest.mark.parametrize("precision,rows", [(512, 2560), (400, 1000), (768, 600), (1024, 600), (256, 600), (2048, 300)])
+def test_int_syrk_with_every_entry_at_the_largest_magnitude_over_one_sweep(precision, rows, monkeypatch):
+    """parity.check_int_syrk_extremes: one row split (at 512 bits the longest sweep the host ever launches, 2560 rows), every
+    limb of every piece at its maximum: the inputs that decide whether the carry schedule of the column sums holds."""
+    monkeypatch.setenv("SDPB_HIP_SYRK_SPLITS", "1")
+    sdp, _, _, _ = parity.load_case("1d")
+    s = _solver(sdp, precision)
+    parity.check_int_syrk_extremes(s, rows, 37)
+    s.close()
+
+
 # ---- BASELINE.json config C1 at its stated --precision 128 (whole iterations at 6 limbs)
 def test_config_C1_at_its_stated_precision_128():
     assert parity.check_c1_at_precision_128(libs.product_lib()) <= -64
