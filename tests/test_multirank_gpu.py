@@ -44,7 +44,7 @@ def _load(case):
         from sdpb_amd import synthetic
         name, _, scale = case.partition("x")
         c = synthetic.config(name, float(scale) if scale else 1.0)
-        sdp, src = synthetic.make_lazy(c["dims"], c["num_points"], c["N"], c["precision"], c["seed"])
+        sdp, src = synthetic.make_lazy(c["dims"], c["num_points"], c["N"], c["precision"], c["seed"], feasible=c.get("feasible", False))
         return sdp, c["precision"], dict(parity.DEFAULT_PARAMS), src, None
     sdp, meta, iters, _ = parity.load_case(case)
     return sdp, meta["precision"], meta["params"], None, iters
@@ -201,6 +201,28 @@ def test_cholesky_Q_distributed_over_the_ranks_on_the_device(world, case, n_iter
         bad, _ = parity.compare_iteration(results[0][2][it], o.scalars(), tol_bits=precision // 2)
         assert not bad, (it + 1, bad)
     o.close()
+
+
+@pytest.mark.gpu
+def test_two_ranks_follow_the_run_to_optimality():
+    """The strictly feasible fixture (C4f x0.25: J = 150, N = 250, 159 oracle iterations before 'found primal-dual optimal
+    solution') on two ranks sharing the GPU: the end game of a convergent run -- step lengths from spectra that collapse onto
+    one point, reduced over the ranks; block condition numbers past 2^(p/2) -- with the cross-rank sums in the loop.  Every
+    iteration against the committed oracle record at the bar of the one-rank fixture test (2^-(p/2), conditioned past
+    cond = 2^(p/2-16)); ranks bit-identical."""
+    import json
+    with open(os.path.join(parity.GOLDEN, "synthetic", "C4f_x0.25_to_termination.json")) as f:
+        fx = json.load(f)
+    sdp, precision, params, src, _ = _load("C4fx0.25")
+    assert sdp.J == fx["J"] and sdp.N == fx["N"] and precision == fx["precision"]
+    results = run_ranks(2, "C4fx0.25", len(fx["iterations"]), timeout=1500)
+    check_ranks(results, 2, sdp.J)
+    worst = float("-inf")
+    for got, rec in zip(results[0][2], fx["iterations"]):
+        bad, w = parity.compare_iteration(got, rec, tol_bits=parity.conditioned_tol_bits(rec, precision, precision // 2))
+        worst = max(worst, w)
+        assert not bad, (rec["iteration"], bad)
+    print(f"two ranks, {len(fx['iterations'])} iterations of the run to optimality: worst log2 rel diff {worst:.1f}")
 
 
 @pytest.mark.gpu
