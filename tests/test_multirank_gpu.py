@@ -204,7 +204,8 @@ def test_cholesky_Q_distributed_over_the_ranks_on_the_device(world, case, n_iter
 
 
 @pytest.mark.gpu
-def test_two_ranks_follow_the_run_to_optimality():
+@pytest.mark.parametrize("transport", ["callbacks", "rccl-one-gpu"])
+def test_two_ranks_follow_the_run_to_optimality(transport):
     """The strictly feasible fixture (C4f x0.25: J = 150, N = 250, 159 oracle iterations before 'found primal-dual optimal
     solution') on two ranks sharing the GPU: the end game of a convergent run -- step lengths from spectra that collapse onto
     one point, reduced over the ranks; block condition numbers past 2^(p/2) -- with the cross-rank sums in the loop.  Every
@@ -215,8 +216,8 @@ def test_two_ranks_follow_the_run_to_optimality():
         fx = json.load(f)
     sdp, precision, params, src, _ = _load("C4fx0.25")
     assert sdp.J == fx["J"] and sdp.N == fx["N"] and precision == fx["precision"]
-    results = run_ranks(2, "C4fx0.25", len(fx["iterations"]), timeout=1500)
-    check_ranks(results, 2, sdp.J)
+    results = run_ranks(2, "C4fx0.25", len(fx["iterations"]), timeout=1500, transport=transport)   # host callbacks / in-library RCCL
+    check_ranks(results, 2, sdp.J, transport=transport)
     worst = float("-inf")
     for got, rec in zip(results[0][2], fx["iterations"]):
         bad, w = parity.compare_iteration(got, rec, tol_bits=parity.conditioned_tol_bits(rec, precision, precision // 2))
